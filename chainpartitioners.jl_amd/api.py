@@ -1,0 +1,259 @@
+"""partition_stripe / pack_stripe / oracle_stripe / bound_stripe / total_value /
+bottleneck_value -- the reference's dispatch API for the hot path, host side.
+
+Each function marshals its Julia-shaped arguments into the flat C structs of
+include/chainpart_types.h and calls a backend.  The product backend is the HIP C-ABI
+library (`_lib.HipBackend`, libchainpart.so); there is no CPU fallback in this package --
+if the library or a GPU is missing the call raises.  Tests inject the CPU oracle through
+the same `backend=` hook to compare the two on identical marshalled inputs.
+
+Reference entry points mirrored (under /root/reference/src):
+  partition_stripe  EquiPartitioner.jl:5, DynamicSplitter.jl:15,52,206,260,
+                    BisectCostBottleneckSplitter.jl:6,70, ConvexTotalChunker.jl:26,170
+  pack_stripe       EquiPartitioner.jl:15, DynamicChunker.jl:15,20, ConvexTotalChunker.jl:9,141
+  oracle_stripe / bound_stripe / total_value / bottleneck_value   Costs.jl:3-66
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import models as M
+from .types import (SparseMatrixCSC, SplitPartition, MapPartition, DomainPartition, StepHint, NoHint, to_map)
+
+_default_backend = None
+
+
+def set_default_backend(b):
+    global _default_backend
+    _default_backend = b
+
+
+def get_backend(backend=None):
+    if backend is not None:
+        return backend
+    global _default_backend
+    if _default_backend is None:
+        from ._lib import HipBackend
+        _default_backend = HipBackend()          # raises loudly if the HIP library / GPU is absent
+    return _default_backend
+
+
+class CPError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"chainpart status {code}: {msg}")
+        self.code = code
+
+
+def _check(rc, what, backend):
+    if rc == M.CP_OK or rc == M.CP_INFEASIBLE:
+        return rc
+    msg = backend.last_error() if hasattr(backend, "last_error") else ""
+    if rc == M.CP_EINVAL:
+        raise AssertionError(f"{what}: violated precondition ({msg})")   # Julia: AssertionError
+    if rc == M.CP_EUNSUPPORTED:
+        raise NotImplementedError(f"{what}: no method for this (method, model) pair ({msg})")
+    raise CPError(rc, f"{what}: {msg}")
+
+
+def _rowpart(Pi, need_spl=False):
+    """Marshal an optional row partition -> (cp_rowpart_t | None, keepalive)."""
+    if Pi is None:
+        return None, []
+    rp = M.cp_rowpart_t()
+    keep = []
+    rp.K = Pi.K
+    if isinstance(Pi, SplitPartition):
+        spl = np.ascontiguousarray(Pi.spl, dtype=np.int64)
+        asg = to_map(Pi).asg
+        keep += [spl, asg]
+        rp.spl = spl.ctypes.data
+        rp.asg = asg.ctypes.data
+    elif isinstance(Pi, MapPartition):
+        asg = np.ascontiguousarray(Pi.asg, dtype=np.int64)
+        keep += [asg]
+        rp.asg = asg.ctypes.data
+        rp.spl = None
+    else:
+        raise TypeError("row partition must be a SplitPartition or MapPartition")
+    return rp, keep
+
+
+def _w_table_for(A, f, weight, w_max):
+    """Tabulation length for closures: widths never exceed the constraint, else n."""
+    if weight is not None and isinstance(weight, M.VertexCount):
+        return int(w_max) + 1
+    return A.n + 1
+
+
+def _marshal(A, f, Pi):
+    mdl, weight, w_max = M.split_constraint(f)
+    wt = _w_table_for(A, mdl, weight, w_max)
+    if isinstance(mdl, M.BlockComponentCostModel):
+        ut = A.m + 1
+        mm = mdl.marshal(w_table=wt) if mdl.u_table is not None else _marshal_block(mdl, wt, ut)
+    else:
+        mm = mdl.marshal(w_table=wt)
+    wm = weight.marshal() if weight is not None else None
+    wmax_i = int(w_max) if weight is not None and (weight.dtype == M.CP_I64) else 0
+    wmax_f = float(w_max) if weight is not None else 0.0
+    rp, keep = _rowpart(Pi)
+    return mdl, mm, wm, wmax_i, wmax_f, rp, keep
+
+
+def _marshal_block(mdl, wt, ut):
+    old = (mdl.w_table, mdl.u_table)
+    mdl.w_table, mdl.u_table = wt, ut
+    try:
+        return mdl.marshal()
+    finally:
+        mdl.w_table, mdl.u_table = old
+
+
+# ---------------------------------------------------------------- partition_stripe
+def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) -> SplitPartition:
+    K = int(K)
+    if isinstance(method, M.EquiSplitter):
+        # closed form, O(K) host arithmetic (EquiPartitioner.jl:7)
+        n = A.n
+        k = np.arange(0, K + 1, dtype=np.int64)
+        return SplitPartition(K, k * (n // K) + np.minimum(n % K, k) + 1)
+    b = get_backend(backend)
+    if isinstance(method, (M.DynamicTotalSplitter, M.DynamicBottleneckSplitter,
+                           M.DynamicTotalChunker, M.DynamicBottleneckChunker)):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_dynamic(A, K, method.combine, method.order, mm, rp, wm, wi, wf, spl)
+        _check(rc, "partition_stripe(Dynamic*)", b)
+        return SplitPartition(K, spl)
+    if isinstance(method, M.BisectCostBottleneckSplitter):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, None)
+        if wm is not None:
+            raise NotImplementedError("BisectCost on a ConstrainedCost errors in the reference (Costs.jl:150)")
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_bisect_cost(A, K, mm, method.eps, method.flip, spl)
+        _check(rc, "partition_stripe(BisectCost)", b)
+        return SplitPartition(K, spl)
+    if isinstance(method, M.ConvexTotalSplitter):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_convex(A, K, mm, rp, wm, wi, wf, spl)
+        _check(rc, "partition_stripe(ConvexTotalSplitter)", b)
+        return SplitPartition(K, spl)
+    raise NotImplementedError(f"partition_stripe: method {type(method).__name__} is outside the hot path")
+
+
+# ---------------------------------------------------------------- pack_stripe
+def pack_stripe(A: SparseMatrixCSC, method, Pi=None, *, backend=None) -> SplitPartition:
+    if isinstance(method, M.EquiChunker):
+        n, w = A.n, method.w
+        spl = np.concatenate([np.arange(1, n + 1, w, dtype=np.int64), [n + 1]])   # [1:w:n; n+1]
+        return SplitPartition(len(spl) - 1, spl)
+    b = get_backend(backend)
+    if isinstance(method, M.DynamicTotalChunker):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(A.n + 1, dtype=np.int64)
+        Kout = np.zeros(1, dtype=np.int64)
+        rc = b.pack_dynamic(A, mm, rp, wm, wi, wf, spl, Kout)
+        _check(rc, "pack_stripe(DynamicTotalChunker)", b)
+        return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
+    if isinstance(method, M.ConvexTotalChunker):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(A.n + 1, dtype=np.int64)
+        Kout = np.zeros(1, dtype=np.int64)
+        rc = b.pack_convex(A, mm, rp, wm, wi, wf, spl, Kout)
+        _check(rc, "pack_stripe(ConvexTotalChunker)", b)
+        return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
+    raise NotImplementedError(f"pack_stripe: method {type(method).__name__} is outside the hot path")
+
+
+# ---------------------------------------------------------------- oracles / scoring
+class Oracle:
+    """Callable cost oracle ocl(j, j', k...) (vectorised over arrays of queries)."""
+
+    def __init__(self, hint, mdl, A, Pi, backend):
+        self.hint, self.mdl, self.A, self.Pi, self.backend = hint, mdl, A, Pi, backend
+
+    def __call__(self, j, jp, k=None):
+        scalar = np.isscalar(j)
+        jj = np.atleast_1d(np.asarray(j, dtype=np.int64))
+        jjp = np.atleast_1d(np.asarray(jp, dtype=np.int64))
+        kk = None if k is None else np.broadcast_to(np.asarray(k, dtype=np.int64), jj.shape).copy()
+        _, mm, _, _, _, rp, keep = _marshal(self.A, self.mdl, self.Pi)
+        out = np.zeros(jj.shape, dtype=self.mdl.cost_dtype())
+        rc = self.backend.oracle_eval(self.A, mm, rp, self.hint.code, jj, jjp, kk, out)
+        _check(rc, "oracle", self.backend)
+        return out[0].item() if scalar else out
+
+
+def oracle_stripe(hint, mdl, A, Pi=None, *, backend=None) -> Oracle:
+    return Oracle(hint, mdl, A, Pi, get_backend(backend))
+
+
+def bound_stripe(A, K, mdl, *, backend=None):
+    b = get_backend(backend)
+    mm = mdl.marshal(w_table=A.n + 1)
+    rc, lo, hi = b.bound_stripe(A, int(K), mm)
+    _check(rc, "bound_stripe", b)
+    return lo, hi
+
+
+def _objective(g, A, Phi, mdl, Pi, backend):
+    b = get_backend(backend)
+    if not isinstance(Phi, SplitPartition):
+        raise NotImplementedError("scoring of non-contiguous partitions is outside the hot path")
+    _, mm, _, _, _, rp, keep = _marshal(A, mdl, Pi)
+    rc, v = b.objective(A, Phi.K, np.ascontiguousarray(Phi.spl, dtype=np.int64), mm, rp, g)
+    _check(rc, "objective", b)
+    return v
+
+
+def total_value(A, Phi, mdl, Pi=None, *, backend=None):
+    """total_value(A, [Pi], Phi, mdl)  Costs.jl:28-29"""
+    return _objective(M.CP_COMBINE_SUM, A, Phi, M.split_constraint(mdl)[0], Pi, backend)
+
+
+def bottleneck_value(A, Phi, mdl, Pi=None, *, backend=None):
+    """bottleneck_value(A, [Pi], Phi, mdl)  Costs.jl:26-27"""
+    return _objective(M.CP_COMBINE_MAX, A, Phi, M.split_constraint(mdl)[0], Pi, backend)
+
+
+# ---------------------------------------------------------------- counting structures
+class CountMatrix:
+    """netcount / selfnetcount / dominancecount object: obj[j, j'] (or obj(i, j)), vectorised."""
+
+    def __init__(self, kind, A, hint, backend):
+        self.kind, self.A, self.hint, self.backend = kind, A, hint, backend
+        self.handle = backend.count_build(kind, A, hint.code)
+
+    def __call__(self, a, b):
+        scalar = np.isscalar(a)
+        aa = np.atleast_1d(np.asarray(a, dtype=np.int64))
+        bb = np.atleast_1d(np.asarray(b, dtype=np.int64))
+        out = np.zeros(aa.shape, dtype=np.int64)
+        rc = self.backend.count_query(self.kind, self.handle, aa, bb, out)
+        _check(rc, "count query", self.backend)
+        return int(out[0]) if scalar else out
+
+    def __getitem__(self, ij):
+        return self(*ij)
+
+    def __del__(self):
+        try:
+            self.backend.count_free(self.kind, self.handle)
+        except Exception:
+            pass
+
+
+def netcount(A, hint=None, *, backend=None):
+    """netcount(hint, A)  SparseColorArrays.jl:57-58"""
+    return CountMatrix("net", A, hint or NoHint(), get_backend(backend))
+
+
+def selfnetcount(A, hint=None, *, backend=None):
+    """selfnetcount(hint, A)  SparseColorArrays.jl:165-166"""
+    return CountMatrix("selfnet", A, hint or NoHint(), get_backend(backend))
+
+
+def dominancecount(A, hint=None, *, backend=None):
+    """dominancecount(hint, A)  SparsePrefixMatrices.jl:438-446 : C[i, j] = #{nonzeros row < i, col < j}"""
+    return CountMatrix("dom", A, hint or NoHint(), get_backend(backend))

@@ -1,0 +1,20 @@
+"""Loader shim: the package directory is literally `chainpartitioners.jl_amd/` (a dot is not
+importable with a plain `import`), so register it under the module name
+`chainpartitioners_jl_amd`.  Usage:  `import cpamd; cp = cpamd.load()`."""
+import importlib.util
+import os
+import sys
+
+_NAME = "chainpartitioners_jl_amd"
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chainpartitioners.jl_amd")
+    spec = importlib.util.spec_from_file_location(_NAME, os.path.join(root, "__init__.py"),
+                                                  submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod

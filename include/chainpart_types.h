@@ -1,0 +1,108 @@
+/*
+ * chainpart_types.h -- plain-C value types shared by the product C-ABI
+ * (include/chainpart.h) and by the test oracle (oracle/orc.h).
+ *
+ * Every struct here is a flat, pointer-and-size description of something the
+ * reference expresses as a Julia struct.  All index VALUES are 1-based, exactly
+ * as Julia stores them (colptr[1] == 1, rowval in 1:m, spl[1] == 1, ...).
+ *
+ * Reference types mirrored (file:line under /root/reference/src):
+ *   AffineWorkModel             WorkCosts.jl:5-17
+ *   AffineConnectivityModel     ConnectivityCosts.jl:7-20
+ *   AffineHyperedgeCutModel     HyperedgeCutCosts.jl:7-21
+ *   ColumnBlockComponentCostModel / BlockComponentCostModel  BlockCosts.jl:1-44
+ *   VertexCount (a weight)      SparseColorArrays.jl:1-6
+ *   FeasibleCost (no weight)    Costs.jl:153-171
+ *   per-part alpha[k] models ("Funky*")  test/test_Partitioners.jl:1-8
+ */
+#ifndef CHAINPART_TYPES_H
+#define CHAINPART_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes returned by every entry point */
+#define CP_OK            0
+#define CP_EINVAL        1   /* bad argument / violated precondition (Julia: AssertionError) */
+#define CP_INFEASIBLE    2   /* width constraint infeasible: degenerate partition [1,..,1,n+1] written
+                                (DynamicSplitter.jl:217-222) */
+#define CP_EHIP          3   /* HIP / RCCL runtime error */
+#define CP_EUNSUPPORTED  4   /* (method, model) pair has no device path; nothing written */
+
+/* cost element type Tc (= the model's Tv) */
+#define CP_I64 0
+#define CP_F64 1
+
+/* model kinds */
+#define CP_MODEL_FEASIBLE       0  /* FeasibleCost(): "no constraint" weight */
+#define CP_MODEL_WORK           1  /* alpha + nv*b_vertex + np*b_pin */
+#define CP_MODEL_CONNECTIVITY   2  /* ... + nets*b_net */
+#define CP_MODEL_HYPEREDGE_CUT  3  /* ... + selfnets*b_self_net + cutnets*b_cut_net */
+#define CP_MODEL_COLBLOCK       4  /* alpha_col(w) + nets*beta_col(w) */
+#define CP_MODEL_BLOCK          5  /* rank-R separable 2-D VBR cost, needs a row partition */
+#define CP_MODEL_VERTEX_COUNT   6  /* VertexCount(): j' - j, always Int */
+
+/* parameter slots of p_i64 / p_f64 */
+#define CP_P_ALPHA      0
+#define CP_P_VERTEX     1
+#define CP_P_PIN        2
+#define CP_P_NET        3   /* connectivity: b_net ; hyperedge: b_self_net */
+#define CP_P_SELF_NET   3
+#define CP_P_CUT_NET    4
+
+#define CP_MAX_R 4
+
+/* block_component(f, w) (BlockCosts.jl:41-44): a number, or a closure/tuple/array
+ * that the host tabulates for w = 0 .. len-1 (closures cannot cross a C ABI). */
+typedef struct cp_component {
+    int32_t is_const;      /* 1: value is c_*; 0: value is table[w] */
+    int32_t _pad;
+    int64_t c_i64;
+    double  c_f64;
+    const void *table;     /* int64_t[len] or double[len] according to the model dtype */
+    int64_t len;
+} cp_component_t;
+
+typedef struct cp_model {
+    int32_t kind;          /* CP_MODEL_* */
+    int32_t dtype;         /* CP_I64 / CP_F64 */
+    int64_t p_i64[5];      /* used when dtype == CP_I64 */
+    double  p_f64[5];      /* used when dtype == CP_F64 */
+    const void *alpha_k;   /* optional per-part alpha[k], k = 1..n_alpha_k (element type = dtype); NULL if none */
+    int64_t n_alpha_k;
+    int32_t R;             /* rank of CP_MODEL_BLOCK (<= CP_MAX_R) */
+    int32_t _pad;
+    cp_component_t alpha_row, alpha_col;
+    cp_component_t beta_row[CP_MAX_R], beta_col[CP_MAX_R];
+} cp_model_t;
+
+/* a row partition Pi handed to block models / partwise counts:
+ * MapPartition.asg (length m, values 1..K) and SplitPartition.spl (length K+1) */
+typedef struct cp_rowpart {
+    int64_t K;
+    const int64_t *asg;    /* may be NULL when only spl is meaningful */
+    const int64_t *spl;    /* may be NULL for a pure MapPartition */
+} cp_rowpart_t;
+
+/* objective combiners: DynamicTotal* uses +, DynamicBottleneck* uses max */
+#define CP_COMBINE_SUM 0
+#define CP_COMBINE_MAX 1
+
+/* loop order of the K-part DP (DynamicSplitter.jl:15-50 vs :52-87) */
+#define CP_ORDER_SPLITTER 0
+#define CP_ORDER_CHUNKER  1
+
+/* access-pattern hints select the counting structure in the reference
+ * (SparsePrefixMatrices.jl:448-458) */
+#define CP_HINT_NONE   0   /* BinaryDominanceCount */
+#define CP_HINT_RANDOM 1   /* BinaryDominanceCount */
+#define CP_HINT_SPARSE 2   /* DominanceCount (radix tree) */
+#define CP_HINT_STEP   3   /* SparseStepwiseDominanceCount */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
