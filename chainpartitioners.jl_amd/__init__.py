@@ -13,6 +13,7 @@ from .models import (AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCu
                      ReferenceTotalSplitter, ReferenceBottleneckSplitter, ReferenceTotalChunker,
                      BisectCostBottleneckSplitter, FlipBisectCostBottleneckSplitter,
                      ConvexTotalChunker, ConvexTotalSplitter)
+from . import _lib  # noqa: F401
 from .api import (partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
                   bottleneck_value, netcount, selfnetcount, dominancecount, set_default_backend,
                   get_backend, CPError)

@@ -1,0 +1,210 @@
+"""ctypes binding of the product C-ABI library libchainpart.so (HIP, gfx950).
+
+No fallback of any kind lives here: if the shared object is missing, or no HIP device is
+visible, construction raises.  The symbols bound are exactly those of include/chainpart.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import models as M
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchainpart.so")
+
+SYMBOLS = [
+    "cp_last_error", "cp_version", "cp_device_count", "cp_csr_create", "cp_csr_create_device", "cp_csr_destroy",
+    "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise",
+    "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
+    "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
+    "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
+]
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(make -C chainpartitioners.jl_amd/csrc); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cp_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(x):
+    return C.c_int64(int(x))
+
+
+_COUNT_KIND = {"dom": 0, "net": 1, "selfnet": 2}
+
+
+class HipBackend:
+    """backend interface of api.py over libchainpart.so (one HIP device per process)."""
+    name = "hip"
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.cp_device_count() <= 0:
+            raise RuntimeError("libchainpart: no HIP device visible (the product path has no CPU fallback)")
+        self.device = int(device)
+        self._handles = {}
+
+    def last_error(self):
+        return (self.lib.cp_last_error() or b"").decode()
+
+    # ---- CSR residency: one device handle per host matrix object, dropped with it
+    def csr(self, A):
+        key = id(A)
+        ent = self._handles.get(key)
+        if ent is not None and ent[0]() is A:
+            return ent[1]
+        h = C.c_void_p()
+        rc = self.lib.cp_csr_create(_i64(A.m), _i64(A.n), _i64(A.nnz), _p(A.colptr), _p(A.rowval), C.c_int32(self.device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cp_csr_create failed ({rc}): {self.last_error()}")
+        lib = self.lib
+        handles = self._handles
+
+        def _drop(_ref, key=key, h=h):
+            handles.pop(key, None)
+            lib.cp_csr_destroy(h)
+        self._handles[key] = (weakref.ref(A, _drop), h)
+        return h
+
+    def csr_from_device(self, m, n, N, colptr_dev_ptr, rowval_dev_ptr):
+        """Handle over colptr/rowval already resident in HBM (1-based int64 device arrays)."""
+        h = C.c_void_p()
+        rc = self.lib.cp_csr_create_device(_i64(m), _i64(n), _i64(N), C.c_void_p(colptr_dev_ptr), C.c_void_p(rowval_dev_ptr),
+                                           C.c_int32(self.device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cp_csr_create_device failed ({rc}): {self.last_error()}")
+        return h
+
+    def csr_destroy(self, h):
+        self.lib.cp_csr_destroy(h)
+
+    def reset_cache(self, A_or_handle):
+        h = A_or_handle if isinstance(A_or_handle, C.c_void_p) else self.csr(A_or_handle)
+        return self.lib.cp_csr_reset_cache(h)
+
+    def set_stream(self, A_or_handle, stream_ptr):
+        h = A_or_handle if isinstance(A_or_handle, C.c_void_p) else self.csr(A_or_handle)
+        return self.lib.cp_set_stream(h, C.c_void_p(stream_ptr))
+
+    def set_option(self, name, value):
+        return self.lib.cp_set_option(name.encode(), _i64(value))
+
+    def _h(self, A):
+        return A if isinstance(A, C.c_void_p) else self.csr(A)
+
+    # ---- partitioners
+    def partition_dynamic(self, A, K, combine, order, mm, rp, wm, wi, wf, spl):
+        return self.lib.cp_partition_dynamic(self._h(A), _i64(K), C.c_int32(combine), C.c_int32(order), mm.ptr,
+                                             C.byref(rp) if rp is not None else None,
+                                             wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
+
+    def pack_dynamic(self, A, mm, rp, wm, wi, wf, spl, Kout):
+        return self.lib.cp_pack_dynamic(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,
+                                        wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
+
+    def partition_bisect_cost(self, A, K, mm, eps, flip, spl):
+        return self.lib.cp_partition_bisect_cost(self._h(A), _i64(K), mm.ptr, C.c_double(eps), C.c_int32(flip), _p(spl))
+
+    def pack_convex(self, A, mm, rp, wm, wi, wf, spl, Kout):
+        return self.lib.cp_pack_convex(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,
+                                       wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
+
+    def partition_convex(self, A, K, mm, rp, wm, wi, wf, spl):
+        return self.lib.cp_partition_convex(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
+                                            wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
+
+    # ---- oracles / scoring
+    def oracle_eval(self, A, mm, rp, hint, j, jp, k, out):
+        oi = out if out.dtype == np.int64 else None
+        of = out if out.dtype == np.float64 else None
+        return self.lib.cp_oracle_eval(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None, C.c_int32(hint),
+                                       _i64(j.size), _p(j), _p(jp), _p(k), _p(oi), _p(of))
+
+    def bound_stripe(self, A, K, mm):
+        li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        rc = self.lib.cp_bound_stripe(self._h(A), _i64(K), mm.ptr, C.byref(li), C.byref(hi), C.byref(lf), C.byref(hf))
+        if mm.struct.dtype == M.CP_I64:
+            return rc, li.value, hi.value
+        return rc, lf.value, hf.value
+
+    def objective(self, A, K, spl, mm, rp, g):
+        oi, of = C.c_int64(), C.c_double()
+        rc = self.lib.cp_objective(self._h(A), _i64(K), _p(spl), mm.ptr, C.byref(rp) if rp is not None else None,
+                                   C.c_int32(g), C.byref(oi), C.byref(of))
+        return rc, (oi.value if mm.struct.dtype == M.CP_I64 else of.value)
+
+    def dynamic_tables(self, A, K, combine, mm, rp):
+        ptr = np.zeros((K, A.n + 1), dtype=np.int64)
+        cst = np.zeros((K, A.n + 1), dtype=np.int64 if mm.struct.dtype == M.CP_I64 else np.float64)
+        rc = self.lib.cp_dynamic_tables(self._h(A), _i64(K), C.c_int32(combine), mm.ptr,
+                                        C.byref(rp) if rp is not None else None, _p(ptr),
+                                        _p(cst) if mm.struct.dtype == M.CP_I64 else None,
+                                        _p(cst) if mm.struct.dtype == M.CP_F64 else None)
+        return rc, ptr.T, cst.T
+
+    # ---- counting structures
+    def count_build(self, kind, A, hint):
+        h = C.c_void_p()
+        rc = self.lib.cp_count_build(self._h(A), C.c_int32(_COUNT_KIND[kind]), C.c_int32(hint), C.byref(h))
+        if rc != 0:
+            raise NotImplementedError(f"cp_count_build({kind}) -> {rc}: {self.last_error()}")
+        return h
+
+    def count_query(self, kind, h, a, b, out):
+        return self.lib.cp_count_query(h, _i64(a.size), _p(a), _p(b), _p(out))
+
+    def count_free(self, kind, h):
+        self.lib.cp_count_destroy(h)
+
+    def link_array(self, A):
+        out = np.zeros(max(A.nnz, 1), dtype=np.int64)
+        rc = self.lib.cp_link_array(self._h(A), _p(out))
+        if rc != 0:
+            raise RuntimeError(self.last_error())
+        return out[:A.nnz]
+
+    def partwise(self, A, K, asg):
+        asg = np.ascontiguousarray(asg, dtype=np.int64)
+        npr = C.c_int64()
+        pios = np.zeros(K + 1, dtype=np.int64)
+        prm = np.zeros(max(A.nnz, 1), dtype=np.int64)
+        pos = np.zeros(A.nnz + 1, dtype=np.int64)
+        idx = np.zeros(max(A.nnz, 1), dtype=np.int64)
+        rc = self.lib.cp_partwise(self._h(A), _i64(K), _p(asg), C.byref(npr), _p(pios), _p(prm), _p(pos), _p(idx))
+        if rc != 0:
+            raise NotImplementedError(f"cp_partwise -> {rc}: {self.last_error()}")
+        n = npr.value
+        return n, pios, prm[:n].copy(), pos[:n + 1].copy(), idx[:A.nnz].copy()
+
+    # ---- measurement
+    def prof_enable(self, on=True):
+        self.lib.cp_prof_enable(C.c_int32(1 if on else 0))
+
+    def prof_reset(self):
+        self.lib.cp_prof_reset()
+
+    def prof_get(self):
+        out = {}
+        name = C.c_char_p()
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        nslots = self.lib.cp_prof_get(C.c_int32(0), C.byref(name), C.byref(n), C.byref(ms), C.byref(by))
+        for s in range(nslots):
+            self.lib.cp_prof_get(C.c_int32(s), C.byref(name), C.byref(n), C.byref(ms), C.byref(by))
+            out[name.value.decode()] = {"launches": n.value, "ms": ms.value, "units": by.value}
+        return out

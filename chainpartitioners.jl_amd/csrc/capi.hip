@@ -1,0 +1,491 @@
+// capi.hip -- extern "C" entry points of libchainpart.so (include/chainpart.h) and the DP drivers.
+#include "csr.hpp"
+#include "model.hpp"
+#include "dp.hpp"
+#include <cmath>
+#include <memory>
+
+using namespace cpk;
+
+namespace cpk {
+
+// ------------------------------------------------------------------ small kernels used by the drivers
+// per-column count of entries whose previous occurrence lies before `thr` (thr = 0: first occurrences)
+__global__ void k_col_count_prev_lt(const int64_t *__restrict__ pos, const int32_t *__restrict__ prev, int32_t thr,
+                                    int32_t *__restrict__ out, int64_t n)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int32_t k = 0;
+    for (int64_t q = pos[c]; q < pos[c + 1]; q++) k += (prev[q] < thr);
+    out[c] = k;
+}
+
+// layer 1: cst[r] = f(1, j', 1) with nets(0, r) = #first occurrences in columns [0, r)   (DynamicSplitter.jl:26-31)
+template <typename TC>
+__global__ void k_layer1(int64_t n, const int64_t *__restrict__ pos, const int64_t *__restrict__ firsts_before,
+                         const int64_t *__restrict__ lpos, DevModel<TC> M, TC alpha, TC *__restrict__ cst, int32_t *__restrict__ ptr)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    int64_t nn = firsts_before ? firsts_before[r] : 0;
+    int64_t nl = (M.kind == CP_MODEL_HYPEREDGE_CUT) ? lpos[r] : 0;     // rows whose last column < r
+    cst[r] = dm_apply(M, alpha, r, pos[r], nn, nl);
+    ptr[r] = 0;
+}
+
+// counts for one (p, r) range per block: nets = #{q in cols [p,r) : prev[q] < p},
+// selfnets = #{rows with first in [p,r) and last < r}
+__global__ void __launch_bounds__(256) k_range_counts(int64_t nq, const int64_t *__restrict__ P, const int64_t *__restrict__ Rr,
+                                                      const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
+                                                      const int64_t *__restrict__ fpos, const int32_t *__restrict__ flast,
+                                                      int64_t *__restrict__ nets, int64_t *__restrict__ selfnets)
+{
+    int64_t i = blockIdx.x;
+    if (i >= nq) return;
+    __shared__ int64_t sh[256];
+    int64_t p = P[i], r = Rr[i];
+    int64_t c = 0;
+    if (r > p) {
+        int64_t q0 = pos[p], q1 = pos[r];
+        int32_t thr = (int32_t)p;
+        for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) c += (prev[q] < thr);
+    }
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < (unsigned)o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) nets[i] = sh[0];
+    __syncthreads();
+    if (selfnets) {
+        c = 0;
+        if (r > p) {
+            int64_t s0 = fpos[p], s1 = fpos[r];
+            int32_t thr = (int32_t)r;
+            for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) c += (flast[s] < thr);
+        }
+        sh[threadIdx.x] = c;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < (unsigned)o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) selfnets[i] = sh[0];
+    }
+}
+
+template <typename TC>
+__global__ void k_apply_model(int64_t nq, const int64_t *__restrict__ P, const int64_t *__restrict__ Rr, const int64_t *__restrict__ Kk,
+                              const int64_t *__restrict__ pos, const int64_t *__restrict__ nets, const int64_t *__restrict__ selfnets,
+                              DevModel<TC> M, TC *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int64_t p = P[i], r = Rr[i];
+    TC alpha = dm_alpha(M, Kk ? Kk[i] : (int64_t)0);
+    out[i] = dm_apply(M, alpha, r - p, pos[r] - pos[p], nets ? nets[i] : (int64_t)0, selfnets ? selfnets[i] : (int64_t)0);
+}
+
+// ------------------------------------------------------------------ helpers
+template <typename F>
+static int32_t guarded(F &&f)
+{
+    try { return f(); }
+    catch (const HipFail &e) { return e.code; }
+    catch (const std::bad_alloc &) { set_error("host allocation failed"); return CP_EHIP; }
+}
+
+static bool model_known(const cp_model_t *m)
+{
+    return m && m->kind >= CP_MODEL_FEASIBLE && m->kind <= CP_MODEL_VERTEX_COUNT && (m->dtype == CP_I64 || m->dtype == CP_F64);
+}
+
+static bool all_integral(const cp_model_t *m)
+{
+    if (m->dtype == CP_I64) return true;
+    for (int i = 0; i < 5; i++) if (std::floor(m->p_f64[i]) != m->p_f64[i] || std::fabs(m->p_f64[i]) > 9e15) return false;
+    if (m->alpha_k) for (int64_t i = 0; i < m->n_alpha_k; i++) { double v = ((const double *)m->alpha_k)[i]; if (std::floor(v) != v) return false; }
+    return true;
+}
+
+// is the O(n log^2 n) total-cost scheme exact for this model?  Needs W[p]+f(p,r) inverse-Monge:
+// modular terms (alpha, vertices, pins) are free; the net count is submodular, so beta_net >= 0;
+// hyperedge cost = d*b_cut + l*(b_self - b_cut) needs b_cut >= 0 and b_self <= b_cut.
+// Float64 models qualify only when every parameter is integer-valued (then all sums are exact).
+static bool fast_total_ok(const cp_model_t *m)
+{
+    if (!all_integral(m)) return false;
+    auto P = [&](int i) { return m->dtype == CP_I64 ? (double)m->p_i64[i] : m->p_f64[i]; };
+    if (m->kind == CP_MODEL_WORK) return true;
+    if (m->kind == CP_MODEL_CONNECTIVITY) return P(CP_P_NET) >= 0;
+    return false;
+}
+
+template <typename TC> static TC host_alpha(const cp_model_t *m, int64_t k)
+{
+    if (m->alpha_k && k >= 1 && k <= m->n_alpha_k) return ((const TC *)m->alpha_k)[k - 1];
+    return model_param<TC>(m, CP_P_ALPHA);
+}
+
+// ------------------------------------------------------------------ the K-part DP driver (unconstrained)
+template <typename TC>
+static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, const cp_model_t *mdl,
+                           int64_t *spl_out, int64_t *ptr_tab, TC *cst_tab)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
+    bool fast = combine == CP_COMBINE_SUM && fast_total_ok(mdl) && !g_opt_force_brute;
+    if (!fast)
+        CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
+                   "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
+    ensure_links(A);
+    if (need_self) ensure_self(A);
+    HostModel<TC> HM;
+    build_dev_model<TC>(mdl, HM, s);
+    size_t n1 = (size_t)n + 1;
+    DBuf<TC> cstA(n1), cstB(n1);
+    DBuf<int32_t> ptr((size_t)K * n1);
+    DBuf<int32_t> cnt0((size_t)(n > 0 ? n : 1));
+    DBuf<int64_t> firsts(n1), scratch;
+    // layer 1
+    bool has_nets = mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_HYPEREDGE_CUT || mdl->kind == CP_MODEL_COLBLOCK;
+    if (has_nets) {
+        if (n > 0) hipLaunchKernelGGL(k_col_count_prev_lt, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, A->pos.p, A->prev.p, 0, cnt0.p, n);
+        exclusive_scan_i32(cnt0.p, firsts.p, n, scratch, s);
+    }
+    // splitter order passes the part index (per-part alpha[k]); the chunker loop order calls f(j,j') (DynamicSplitter.jl:64)
+    auto alpha_of = [&](int64_t k) { return order == CP_ORDER_SPLITTER ? host_alpha<TC>(mdl, k) : model_param<TC>(mdl, CP_P_ALPHA); };
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_layer1<TC>), dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, A->pos.p,
+                       has_nets ? firsts.p : nullptr, need_self ? A->lpos.p : nullptr, HM.d, alpha_of(1), cstA.p, ptr.p);
+    CP_HIP(hipGetLastError());
+    auto dump_layer = [&](int64_t k, const TC *cst_dev, bool last_only) {
+        if (!ptr_tab) return;
+        std::vector<TC> hc(n1);
+        std::vector<int32_t> hp(n1);
+        CP_HIP(hipMemcpyAsync(hc.data(), cst_dev, sizeof(TC) * n1, hipMemcpyDeviceToHost, s));
+        CP_HIP(hipMemcpyAsync(hp.data(), ptr.p + (size_t)(k - 1) * n1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+        CP_HIP(hipStreamSynchronize(s));
+        for (size_t r = 0; r < n1; r++) {
+            bool keep = !last_only || r == (size_t)n;
+            ptr_tab[(size_t)(k - 1) * n1 + r] = keep ? (int64_t)hp[r] + 1 : 0;               // zeros(Ti, n+1, K)
+            cst_tab[(size_t)(k - 1) * n1 + r] = keep ? hc[r] : CostTraits<TC>::typemax();     // fill(typemax, ...)
+        }
+    };
+    dump_layer(1, cstA.p, false);
+    void *work = fast ? dp_total_work_new<TC>() : nullptr;
+    struct WorkGuard { void *w; ~WorkGuard() { if (w) dp_total_work_free<TC>(w); } } wg{work};
+    TC *prevc = cstA.p, *curc = cstB.p;
+    for (int64_t k = 2; k <= K; k++) {
+        int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
+        bool last = (k == K);
+        if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work);
+        else dp_brute_layer<TC>(A, HM.d, alpha_of(k), combine, prevc, curc, pk, last ? n : 0, n);   // layer K: row n+1 only (:34)
+        dump_layer(k, curc, last);
+        std::swap(prevc, curc);
+    }
+    // unravel_splits (DynamicSplitter.jl:89-99): K dependent single-element reads of ptr
+    std::vector<int64_t> spl((size_t)K + 1);
+    spl[K] = n;
+    for (int64_t k = K; k >= 1; k--) {
+        int32_t v = 0;
+        CP_HIP(hipMemcpyAsync(&v, ptr.p + (size_t)(k - 1) * n1 + (size_t)spl[k], sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CP_HIP(hipStreamSynchronize(s));
+        spl[k - 1] = v;
+    }
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = spl[k] + 1;
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------ ocl(j, j', k) batches
+template <typename TC>
+static int32_t run_oracle_eval(cp_csr_s *A, const cp_model_t *mdl, int64_t nq, const int64_t *j, const int64_t *jp,
+                               const int64_t *k, TC *out)
+{
+    hipStream_t s = A->stream;
+    if (nq <= 0) return CP_OK;
+    bool has_nets = mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_HYPEREDGE_CUT || mdl->kind == CP_MODEL_COLBLOCK;
+    bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
+    if (has_nets) ensure_links(A);
+    if (need_self) ensure_self(A);
+    std::vector<int64_t> hp((size_t)nq), hr((size_t)nq);
+    for (int64_t i = 0; i < nq; i++) {
+        CP_REQUIRE(j[i] >= 1 && jp[i] >= j[i] && jp[i] <= A->n + 1, CP_EINVAL, "oracle query needs 1 <= j <= j' <= n+1");
+        hp[i] = j[i] - 1; hr[i] = jp[i] - 1;
+    }
+    DBuf<int64_t> dP((size_t)nq), dR((size_t)nq), dK, dN, dS;
+    DBuf<TC> dO((size_t)nq);
+    CP_HIP(hipMemcpyAsync(dP.p, hp.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+    CP_HIP(hipMemcpyAsync(dR.p, hr.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+    if (k) { dK.alloc((size_t)nq); CP_HIP(hipMemcpyAsync(dK.p, k, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s)); }
+    if (has_nets) {
+        dN.alloc((size_t)nq);
+        if (need_self) dS.alloc((size_t)nq);
+        ProfScope ps(PROF_QUERY, s, 0.0);
+        hipLaunchKernelGGL(k_range_counts, dim3((unsigned)nq), dim3(256), 0, s, nq, dP.p, dR.p, A->pos.p, A->prev.p,
+                           need_self ? A->fpos.p : nullptr, need_self ? A->flast.p : nullptr, dN.p, need_self ? dS.p : nullptr);
+    }
+    HostModel<TC> HM;
+    build_dev_model<TC>(mdl, HM, s);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_apply_model<TC>), dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, nq, dP.p, dR.p,
+                       k ? dK.p : nullptr, A->pos.p, has_nets ? dN.p : nullptr, need_self ? dS.p : nullptr, HM.d, dO.p);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipMemcpyAsync(out, dO.p, sizeof(TC) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    return CP_OK;
+}
+
+static int64_t fld_i64(int64_t a, int64_t b)
+{
+    int64_t q = a / b, r = a % b;
+    if (r != 0 && ((r < 0) != (b < 0))) q -= 1;
+    return q;
+}
+
+}  // namespace cpk
+
+// =================================================================== extern "C"
+extern "C" {
+
+const char *cp_last_error(void) { return g_last_error.c_str(); }
+int32_t cp_version(void) { return 100; }
+
+int32_t cp_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+static int32_t csr_create_impl(int64_t m, int64_t n, int64_t N, const int64_t *colptr, const int64_t *rowval,
+                               int32_t device, bool on_device, cp_csr_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(out && colptr && (rowval || N == 0), CP_EINVAL, "null argument");
+        CP_REQUIRE(m >= 0 && n >= 0 && N >= 0, CP_EINVAL, "negative dimension");
+        CP_REQUIRE(n < (int64_t)1 << 30 && m < (int64_t)1 << 30 && N < ((int64_t)1 << 31) - 2, CP_EINVAL,
+                   "dimensions exceed the 32-bit link-array layout");
+        CP_REQUIRE(cp_device_count() > 0, CP_EHIP, "no HIP device visible: libchainpart has no CPU fallback");
+        CP_HIP(hipSetDevice(device));
+        std::unique_ptr<cp_csr_s> A(new cp_csr_s());
+        A->device = device; A->m = m; A->n = n; A->N = N;
+        CP_HIP(hipStreamCreate(&A->stream));
+        A->own_stream = true;
+        csr_upload(A.get(), colptr, rowval, on_device);
+        *out = A.release();
+        return CP_OK;
+    });
+}
+
+int32_t cp_csr_create(int64_t m, int64_t n, int64_t N, const int64_t *colptr, const int64_t *rowval, int32_t device, cp_csr_t *out)
+{
+    if (colptr && n >= 0 && (colptr[0] != 1 || colptr[n] != N + 1)) { set_error("colptr must be 1-based with colptr[n+1] == nnz+1"); return CP_EINVAL; }
+    return csr_create_impl(m, n, N, colptr, rowval, device, false, out);
+}
+
+int32_t cp_csr_create_device(int64_t m, int64_t n, int64_t N, const int64_t *colptr_device, const int64_t *rowval_device,
+                             int32_t device, cp_csr_t *out)
+{
+    return csr_create_impl(m, n, N, colptr_device, rowval_device, device, true, out);
+}
+
+int32_t cp_csr_destroy(cp_csr_t A)
+{
+    if (!A) return CP_OK;
+    (void)hipSetDevice(A->device);
+    if (A->stream) (void)hipStreamSynchronize(A->stream);
+    if (A->own_stream && A->stream) (void)hipStreamDestroy(A->stream);
+    delete A;
+    return CP_OK;
+}
+
+int32_t cp_csr_reset_cache(cp_csr_t A)
+{
+    if (!A) return CP_EINVAL;
+    return guarded([&]() -> int32_t { CP_HIP(hipStreamSynchronize(A->stream)); drop_cache(A); return CP_OK; });
+}
+
+int32_t cp_set_stream(cp_csr_t A, void *hip_stream)
+{
+    if (!A) return CP_EINVAL;
+    if (A->own_stream && A->stream) { (void)hipStreamSynchronize(A->stream); (void)hipStreamDestroy(A->stream); }
+    A->stream = (hipStream_t)hip_stream;
+    A->own_stream = false;
+    return CP_OK;
+}
+
+int32_t cp_set_option(const char *name, int64_t value)
+{
+    if (!name) return CP_EINVAL;
+    if (!strcmp(name, "force_brute")) { g_opt_force_brute = value; return CP_OK; }
+    if (!strcmp(name, "brute_max_n")) { g_opt_brute_max_n = value; return CP_OK; }
+    set_error("unknown option");
+    return CP_EINVAL;
+}
+
+int32_t cp_prof_enable(int32_t on) { g_prof_on = on != 0; return CP_OK; }
+int32_t cp_prof_reset(void)
+{
+    for (auto &p : g_prof) { p.launches = 0; p.ms = 0; p.alg_bytes = 0; }
+    return CP_OK;
+}
+int32_t cp_prof_get(int32_t slot, const char **name, int64_t *launches, double *total_ms, double *alg_bytes)
+{
+    if (slot >= 0 && slot < PROF_NSLOTS) {
+        if (name) *name = g_prof[slot].name;
+        if (launches) *launches = g_prof[slot].launches;
+        if (total_ms) *total_ms = g_prof[slot].ms;
+        if (alg_bytes) *alg_bytes = g_prof[slot].alg_bytes;
+    }
+    return PROF_NSLOTS;
+}
+
+int32_t cp_partition_equi(int64_t n, int64_t K, int64_t *spl_out)
+{
+    if (K < 1 || n < 0 || !spl_out) return CP_EINVAL;
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = k * (n / K) + ((n % K) < k ? (n % K) : k) + 1;   // EquiPartitioner.jl:7
+    return CP_OK;
+}
+
+int32_t cp_pack_equi(int64_t n, int64_t w, int64_t *spl_out, int64_t *K_out)
+{
+    if (w < 1 || n < 0 || !spl_out || !K_out) return CP_EINVAL;
+    int64_t K = 0;
+    for (int64_t j = 1; j <= n; j += w) spl_out[K++] = j;                                           // EquiPartitioner.jl:20
+    spl_out[K] = n + 1;
+    *K_out = K;
+    return CP_OK;
+}
+
+int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t order, const cp_model_t *model,
+                             const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64, double wmax_f64, int64_t *spl_out)
+{
+    (void)wmax_i64; (void)wmax_f64; (void)Pi;
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && spl_out && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
+        CP_HIP(hipSetDevice(A->device));
+        bool constrained = weight && weight->kind != CP_MODEL_FEASIBLE;
+        CP_REQUIRE(!constrained, CP_EUNSUPPORTED, "ConstrainedCost DP variants are not on the device path yet");
+        CP_REQUIRE(model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT ||
+                       model->kind == CP_MODEL_COLBLOCK,
+                   CP_EUNSUPPORTED, "model kind has no device DP path yet");
+        if (model->dtype == CP_I64) return run_dynamic<int64_t>(A, K, combine, order, model, spl_out, nullptr, nullptr);
+        return run_dynamic<double>(A, K, combine, order, model, spl_out, nullptr, nullptr);
+    });
+}
+
+int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model_t *model, const cp_rowpart_t *Pi,
+                          int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+{
+    (void)Pi;
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && ptr_out && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        std::vector<int64_t> spl((size_t)K + 1);
+        if (model->dtype == CP_I64) return run_dynamic<int64_t>(A, K, combine, CP_ORDER_SPLITTER, model, spl.data(), ptr_out, cst_i64);
+        return run_dynamic<double>(A, K, combine, CP_ORDER_SPLITTER, model, spl.data(), ptr_out, cst_f64);
+    });
+}
+
+int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint, int64_t nq,
+                       const int64_t *j, const int64_t *jp, const int64_t *k, int64_t *out_i64, double *out_f64)
+{
+    (void)hint; (void)Pi;
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && model_known(model) && (nq == 0 || (j && jp)), CP_EINVAL, "bad argument");
+        CP_REQUIRE(model->kind != CP_MODEL_BLOCK, CP_EUNSUPPORTED, "BlockComponentCostModel oracle is not on the device path yet");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_oracle_eval<int64_t>(A, model, nq, j, jp, k, out_i64);
+        return run_oracle_eval<double>(A, model, nq, j, jp, k, out_f64);
+    });
+}
+
+int32_t cp_objective(cp_csr_t A, int64_t K, const int64_t *spl, const cp_model_t *model, const cp_rowpart_t *Pi,
+                     int32_t combine, int64_t *out_i64, double *out_f64)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && spl && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        std::vector<int64_t> j((size_t)K), jp((size_t)K), kk((size_t)K);
+        for (int64_t k = 0; k < K; k++) { j[k] = spl[k]; jp[k] = spl[k + 1]; kk[k] = k + 1; }
+        if (model->dtype == CP_I64) {
+            std::vector<int64_t> v((size_t)K);
+            int32_t rc = cp_oracle_eval(A, model, Pi, CP_HINT_STEP, K, j.data(), jp.data(), kk.data(), v.data(), nullptr);
+            if (rc != CP_OK) return rc;
+            int64_t acc = combine == CP_COMBINE_SUM ? 0 : INT64_MIN;                  // objective_identity Costs.jl:23-24
+            for (int64_t k = 0; k < K; k++) acc = combine == CP_COMBINE_SUM ? cadd(acc, v[k]) : (acc > v[k] ? acc : v[k]);
+            *out_i64 = acc;
+        } else {
+            std::vector<double> v((size_t)K);
+            int32_t rc = cp_oracle_eval(A, model, Pi, CP_HINT_STEP, K, j.data(), jp.data(), kk.data(), nullptr, v.data());
+            if (rc != CP_OK) return rc;
+            double acc = combine == CP_COMBINE_SUM ? 0.0 : -INFINITY;
+            for (int64_t k = 0; k < K; k++) acc = combine == CP_COMBINE_SUM ? acc + v[k] : (acc > v[k] ? acc : v[k]);
+            *out_f64 = acc;
+        }
+        return CP_OK;
+    });
+}
+
+int32_t cp_bound_stripe(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        int64_t n = A->n, N = A->N;
+        if (model->kind == CP_MODEL_WORK) {                                            // WorkCosts.jl:39-51
+            if (model->dtype == CP_I64) {
+                int64_t a = model->p_i64[0], bv = model->p_i64[1], bp = model->p_i64[2];
+                *lo_i64 = a + fld_i64(bv * n + bp * N, K);
+                if (bv >= 0 && bp >= 0) *hi_i64 = a + bv * n + bp * N;
+                else if (bv <= 0 && bp <= 0) *hi_i64 = a;
+                else { set_error("bound_stripe: mixed-sign work model"); return CP_EINVAL; }
+                *lo_f64 = (double)*lo_i64; *hi_f64 = (double)*hi_i64;
+            } else {
+                double a = model->p_f64[0], bv = model->p_f64[1], bp = model->p_f64[2];
+                *lo_f64 = a + std::floor((bv * (double)n + bp * (double)N) / (double)K);
+                if (bv >= 0 && bp >= 0) *hi_f64 = a + (double)n * bv + (double)N * bp;
+                else if (bv <= 0 && bp <= 0) *hi_f64 = a;
+                else { set_error("bound_stripe: mixed-sign work model"); return CP_EINVAL; }
+            }
+            return CP_OK;
+        }
+        if (model->kind == CP_MODEL_CONNECTIVITY) {                                    // ConnectivityCosts.jl:25-35
+            int64_t one = 1, np1 = n + 1;
+            if (model->dtype == CP_I64) {
+                CP_REQUIRE(model->p_i64[1] >= 0 && model->p_i64[2] >= 0 && model->p_i64[3] >= 0, CP_EINVAL, "bound_stripe asserts beta >= 0");
+                int64_t chi = 0;
+                int32_t rc = cp_oracle_eval(A, model, nullptr, CP_HINT_STEP, 1, &one, &np1, nullptr, &chi, nullptr);
+                if (rc != CP_OK) return rc;
+                *hi_i64 = chi; *lo_i64 = model->p_i64[0] + fld_i64(chi - model->p_i64[0], K);
+                *lo_f64 = (double)*lo_i64; *hi_f64 = (double)*hi_i64;
+            } else {
+                CP_REQUIRE(model->p_f64[1] >= 0 && model->p_f64[2] >= 0 && model->p_f64[3] >= 0, CP_EINVAL, "bound_stripe asserts beta >= 0");
+                double chi = 0;
+                int32_t rc = cp_oracle_eval(A, model, nullptr, CP_HINT_STEP, 1, &one, &np1, nullptr, nullptr, &chi);
+                if (rc != CP_OK) return rc;
+                *hi_f64 = chi; *lo_f64 = model->p_f64[0] + std::floor((chi - model->p_f64[0]) / (double)K);
+            }
+            return CP_OK;
+        }
+        set_error("bound_stripe has no method for this model (the reference raises MethodError)");
+        return CP_EUNSUPPORTED;
+    });
+}
+
+// ---- entry points whose device kernels land in later files; until then they refuse loudly ----
+#define CP_TODO(msg) do { set_error(msg); return CP_EUNSUPPORTED; } while (0)
+
+int32_t cp_link_array(cp_csr_t A, int64_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && out, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        ensure_links(A);
+        std::vector<int32_t> h((size_t)(A->N > 0 ? A->N : 1));
+        CP_HIP(hipMemcpyAsync(h.data(), A->prev.p, sizeof(int32_t) * (size_t)A->N, hipMemcpyDeviceToHost, A->stream));
+        CP_HIP(hipStreamSynchronize(A->stream));
+        for (int64_t q = 0; q < A->N; q++) out[q] = (A->n + 1) - ((int64_t)h[q] + 1);   // idx'[q] = (n+1) - hst[i]
+        return CP_OK;
+    });
+}
+
+}  // extern "C"

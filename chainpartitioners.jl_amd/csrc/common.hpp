@@ -1,0 +1,97 @@
+// common.hpp -- shared device/host utilities of libchainpart (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/chainpart.h"
+
+namespace cpk {
+
+// ------------------------------------------------------------------ errors
+extern thread_local std::string g_last_error;
+inline void set_error(const std::string &s) { g_last_error = s; }
+
+struct HipFail { int32_t code; };
+
+#define CP_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            char _b[512];                                                                   \
+            snprintf(_b, sizeof(_b), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,          \
+                     hipGetErrorString(_e));                                                \
+            cpk::set_error(_b);                                                             \
+            throw cpk::HipFail{CP_EHIP};                                                    \
+        }                                                                                   \
+    } while (0)
+
+#define CP_REQUIRE(cond, code, msg)                                                         \
+    do {                                                                                    \
+        if (!(cond)) { cpk::set_error(msg); throw cpk::HipFail{code}; }                     \
+    } while (0)
+
+// ------------------------------------------------------------------ device buffers (RAII)
+template <typename T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    explicit DBuf(size_t count) { alloc(count); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) CP_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ per-kernel HIP-event profiling
+struct ProfSlot { const char *name; int64_t launches; double ms; double alg_bytes; };
+enum { PROF_EXPAND = 0, PROF_EVAL, PROF_SETUP, PROF_SCAN, PROF_CARRY, PROF_FIX, PROF_COMBINE, PROF_LINKS,
+       PROF_BRUTE, PROF_WAVELET, PROF_QUERY, PROF_BISECT, PROF_CHUNK, PROF_NSLOTS };
+extern ProfSlot g_prof[PROF_NSLOTS];
+extern bool g_prof_on;
+
+struct ProfPending { int slot; hipEvent_t a, b; double bytes; };
+extern std::vector<ProfPending> g_prof_pending;
+extern std::vector<hipEvent_t> g_event_pool;
+
+inline hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e; CP_HIP(hipEventCreate(&e)); return e;
+}
+
+// RAII scope: records an event pair around the launches issued inside it
+struct ProfScope {
+    int slot; hipStream_t s; hipEvent_t a{}, b{}; double bytes; bool on;
+    ProfScope(int slot_, hipStream_t s_, double alg_bytes) : slot(slot_), s(s_), bytes(alg_bytes), on(g_prof_on) {
+        if (on) { a = prof_event(); b = prof_event(); CP_HIP(hipEventRecord(a, s)); }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(b, s); g_prof_pending.push_back({slot, a, b, bytes}); }
+    }
+};
+
+void prof_collect();   // resolve pending event pairs (after a stream sync)
+
+// ------------------------------------------------------------------ device-wide exclusive scan (int32 -> int64)
+// out has n+1 entries: out[i] = sum_{t<i} in[t], out[n] = total.
+void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s);
+
+// wave64 helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace cpk

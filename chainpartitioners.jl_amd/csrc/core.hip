@@ -1,0 +1,289 @@
+// core.hip -- globals, profiling, device-wide scan, CSR residency and link-array construction.
+//
+// Link arrays replace the reference's sequential `hst[i]` sweep (NetCount constructor,
+// /root/reference/src/SparseColorArrays.jl:101-118; SelfNetCount :177-222): prev[q] is the column
+// the reference stores as hst[i] when it visits nonzero q (0-based, -1 for "none"), so the
+// reference's idx'[q] equals (n+1) - (prev[q] + 1).
+#include "csr.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace cpk {
+
+thread_local std::string g_last_error;
+ProfSlot g_prof[PROF_NSLOTS] = {
+    {"dp_expand_steps", 0, 0, 0}, {"dp_eval_candidates", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
+    {"scan", 0, 0, 0}, {"dp_tile_carry", 0, 0, 0}, {"dp_span_fix", 0, 0, 0}, {"dp_combine", 0, 0, 0},
+    {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
+    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}};
+bool g_prof_on = false;
+std::vector<ProfPending> g_prof_pending;
+std::vector<hipEvent_t> g_event_pool;
+
+void prof_collect()
+{
+    for (auto &p : g_prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof[p.slot].launches += 1;
+            g_prof[p.slot].ms += ms;
+            g_prof[p.slot].alg_bytes += p.bytes;
+        }
+        g_event_pool.push_back(p.a);
+        g_event_pool.push_back(p.b);
+    }
+    g_prof_pending.clear();
+}
+
+// ------------------------------------------------------------------ exclusive scan int32 -> int64
+constexpr int SCAN_T = 256;
+constexpr int SCAN_I = 8;
+constexpr int SCAN_TILE = SCAN_T * SCAN_I;
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_reduce(const int32_t *__restrict__ in, int64_t *__restrict__ bsum, int64_t n)
+{
+    __shared__ int64_t sh[SCAN_T / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) if (base + k < n) s += in[base + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < SCAN_T / 64; w++) t += sh[w];
+        bsum[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of bsum[0..nb) in place, total written to bsum[nb]
+__global__ void __launch_bounds__(1024) k_scan_blocksums(int64_t *__restrict__ bsum, int64_t nb)
+{
+    __shared__ int64_t sh[1024];
+    int64_t chunk = (nb + 1023) / 1024;
+    int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < nb ? lo + chunk : nb;
+    int64_t s = 0;
+    for (int64_t i = lo; i < hi; i++) s += bsum[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int64_t v = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t run = sh[threadIdx.x] - s;
+    for (int64_t i = lo; i < hi; i++) { int64_t v = bsum[i]; bsum[i] = run; run += v; }
+    if (threadIdx.x == 1023) bsum[nb] = sh[1023];
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict__ in, int64_t *__restrict__ out,
+                                                       const int64_t *__restrict__ bsum, int64_t n, int64_t nb)
+{
+    __shared__ int64_t sh[SCAN_T];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    int32_t v[SCAN_I];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        int64_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) if (base + k < n) { out[base + k] = run; run += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+
+void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s)
+{
+    if (n <= 0) { CP_HIP(hipMemsetAsync(out, 0, sizeof(int64_t), s)); return; }
+    int64_t nb = cdiv(n, SCAN_TILE);
+    scratch.ensure((size_t)nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
+    CP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ CSR upload / normalisation
+__global__ void k_norm_pos(const int64_t *__restrict__ colptr, int64_t *__restrict__ pos, int64_t n1)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) pos[i] = colptr[i] - 1;
+}
+__global__ void k_norm_row(const int64_t *__restrict__ rowval, int32_t *__restrict__ row, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) row[i] = (int32_t)(rowval[i] - 1);
+}
+
+void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool on_device)
+{
+    hipStream_t s = A->stream;
+    A->pos.alloc((size_t)A->n + 1);
+    A->row.alloc((size_t)(A->N > 0 ? A->N : 1));
+    DBuf<int64_t> tmp_c, tmp_r;
+    const int64_t *dc = colptr, *dr = rowval;
+    if (!on_device) {
+        tmp_c.alloc((size_t)A->n + 1);
+        tmp_r.alloc((size_t)(A->N > 0 ? A->N : 1));
+        CP_HIP(hipMemcpyAsync(tmp_c.p, colptr, sizeof(int64_t) * (size_t)(A->n + 1), hipMemcpyHostToDevice, s));
+        if (A->N > 0) CP_HIP(hipMemcpyAsync(tmp_r.p, rowval, sizeof(int64_t) * (size_t)A->N, hipMemcpyHostToDevice, s));
+        dc = tmp_c.p; dr = tmp_r.p;
+    }
+    hipLaunchKernelGGL(k_norm_pos, dim3((unsigned)cdiv(A->n + 1, 256)), dim3(256), 0, s, dc, A->pos.p, A->n + 1);
+    if (A->N > 0)
+        hipLaunchKernelGGL(k_norm_row, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, dr, A->row.p, A->N);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------ link arrays
+// col[q]: one wave per 64 columns would idle on skew; a flat binary search per nonzero is regular.
+__global__ void k_fill_col(const int64_t *__restrict__ pos, int32_t *__restrict__ col, int64_t n, int64_t N)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    int64_t lo = 0, hi = n;            // largest c with pos[c] <= q
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (pos[mid] <= q) lo = mid; else hi = mid;
+    }
+    col[q] = (int32_t)lo;
+}
+
+__global__ void k_iota(uint32_t *__restrict__ v, int64_t N)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) v[q] = (uint32_t)q;
+}
+
+// sorted by (row, column): neighbours in the sorted order are the previous / next occurrence of a row
+__global__ void k_links(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sq,
+                        const int32_t *__restrict__ col, int32_t *__restrict__ prev, int32_t *__restrict__ next,
+                        int32_t *__restrict__ rfirst, int32_t *__restrict__ rlast,
+                        int64_t N, int32_t n)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    uint32_t r = skey[s], q = sq[s];
+    int32_t c = col[q];
+    bool first = (s == 0) || skey[s - 1] != r;
+    bool last = (s + 1 == N) || skey[s + 1] != r;
+    prev[q] = first ? -1 : col[sq[s - 1]];
+    next[q] = last ? n : col[sq[s + 1]];
+    if (first) rfirst[r] = c;
+    if (last) rlast[r] = c;
+}
+
+// tpos[r] = first sorted position whose row >= r (row pointer of the transpose), r = 0..m
+__global__ void k_tpos(const uint32_t *__restrict__ skey, int64_t *__restrict__ tpos, int64_t m, int64_t N)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > m) return;
+    int64_t lo = 0, hi = N;            // first s with skey[s] >= r
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)skey[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    tpos[r] = lo;
+}
+
+void ensure_links(cp_csr_s *A)
+{
+    if (A->have_links) return;
+    hipStream_t s = A->stream;
+    int64_t N = A->N, n = A->n, m = A->m;
+    size_t Na = (size_t)(N > 0 ? N : 1);
+    ProfScope ps(PROF_LINKS, s, 8.0 * (double)N + 8.0 * (double)(n + 1));
+    A->col.alloc(Na); A->prev.alloc(Na); A->next.alloc(Na);
+    A->rfirst.alloc((size_t)(m > 0 ? m : 1)); A->rlast.alloc((size_t)(m > 0 ? m : 1));
+    A->tpos.alloc((size_t)m + 1); A->tq.alloc(Na);
+    CP_HIP(hipMemsetAsync(A->rfirst.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
+    CP_HIP(hipMemsetAsync(A->rlast.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
+    CP_HIP(hipMemsetAsync(A->tpos.p, 0, sizeof(int64_t) * ((size_t)m + 1), s));
+    if (N > 0) {
+        hipLaunchKernelGGL(k_fill_col, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, A->pos.p, A->col.p, n, N);
+        DBuf<uint32_t> kin(Na), kout(Na), vin(Na);
+        CP_HIP(hipMemcpyAsync(kin.p, A->row.p, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_iota, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, vin.p, N);
+        unsigned end_bit = 1;
+        while (end_bit < 32 && ((uint64_t)1 << end_bit) < (uint64_t)(m > 1 ? m : 2)) end_bit++;
+        size_t tmp_bytes = 0;
+        CP_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin.p, kout.p, vin.p, (uint32_t *)A->tq.p, (size_t)N, 0u, end_bit, s));
+        DBuf<char> tmp(tmp_bytes > 0 ? tmp_bytes : 1);
+        CP_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, kin.p, kout.p, vin.p, (uint32_t *)A->tq.p, (size_t)N, 0u, end_bit, s));
+        hipLaunchKernelGGL(k_links, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, kout.p, (const uint32_t *)A->tq.p,
+                           A->col.p, A->prev.p, A->next.p, A->rfirst.p, A->rlast.p, N, (int32_t)n);
+        hipLaunchKernelGGL(k_tpos, dim3((unsigned)cdiv(m + 1, 256)), dim3(256), 0, s, kout.p, A->tpos.p, m, N);
+        CP_HIP(hipGetLastError());
+        CP_HIP(hipStreamSynchronize(s));   // kin/kout/vin/tmp die here
+    }
+    A->have_links = true;
+}
+
+// ------------------------------------------------------------------ rows bucketed by first / last column
+__global__ void k_count_first_last(const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
+                                   int32_t *__restrict__ cf, int32_t *__restrict__ cl, int64_t m)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m || rfirst[r] < 0) return;
+    atomicAdd(&cf[rfirst[r]], 1);
+    atomicAdd(&cl[rlast[r]], 1);
+}
+__global__ void k_scatter_first_last(const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
+                                     const int64_t *__restrict__ fpos, const int64_t *__restrict__ lpos,
+                                     int32_t *__restrict__ cf, int32_t *__restrict__ cl,
+                                     int32_t *__restrict__ flast, int32_t *__restrict__ lfirst, int64_t m)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m || rfirst[r] < 0) return;
+    // order inside a bucket is irrelevant: only counts of entries below/above a threshold are used
+    int a = atomicAdd(&cf[rfirst[r]], 1);
+    flast[fpos[rfirst[r]] + a] = rlast[r];
+    int b = atomicAdd(&cl[rlast[r]], 1);
+    lfirst[lpos[rlast[r]] + b] = rfirst[r];
+}
+
+void ensure_self(cp_csr_s *A)
+{
+    ensure_links(A);
+    if (A->have_self) return;
+    hipStream_t s = A->stream;
+    int64_t n = A->n, m = A->m;
+    DBuf<int32_t> cf((size_t)n + 1), cl((size_t)n + 1);
+    DBuf<int64_t> scratch;
+    CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
+    CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
+    if (m > 0) hipLaunchKernelGGL(k_count_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p, cf.p, cl.p, m);
+    A->fpos.alloc((size_t)n + 1); A->lpos.alloc((size_t)n + 1);
+    exclusive_scan_i32(cf.p, A->fpos.p, n, scratch, s);
+    exclusive_scan_i32(cl.p, A->lpos.p, n, scratch, s);
+    int64_t tot = 0;
+    CP_HIP(hipMemcpyAsync(&tot, A->fpos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    A->nrows_nonempty = tot;
+    A->flast.alloc((size_t)(tot > 0 ? tot : 1)); A->lfirst.alloc((size_t)(tot > 0 ? tot : 1));
+    CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
+    CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
+    if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,
+                                  A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, m);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipStreamSynchronize(s));
+    A->have_self = true;
+}
+
+void drop_cache(cp_csr_s *A)
+{
+    A->have_links = false; A->have_self = false;
+    A->col.release(); A->prev.release(); A->next.release(); A->rfirst.release(); A->rlast.release();
+    A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release();
+}
+
+}  // namespace cpk

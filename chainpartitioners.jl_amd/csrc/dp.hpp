@@ -1,0 +1,23 @@
+// dp.hpp -- internal interfaces between the DP translation units.
+#pragma once
+#include "csr.hpp"
+#include "model.hpp"
+
+namespace cpk {
+
+// one layer of the total-cost DP by the O(n log^2 n) scheme (dp_total.hip)
+template <typename TC>
+void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work);
+template <typename TC> void *dp_total_work_new();
+template <typename TC> void dp_total_work_free(void *w);
+
+// one layer by the general O(n^2) sweep, any combine / any model sign pattern (dp_brute.hip).
+// rows [r_lo, r_hi] are computed; window (lo/hi per row) optional.
+template <typename TC>
+void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combine, const TC *W, TC *cst_out,
+                    int32_t *ptr_out, int64_t r_lo, int64_t r_hi);
+
+extern int64_t g_opt_force_brute;      // cp_set_option("force_brute", 1)
+extern int64_t g_opt_brute_max_n;      // largest n the O(n^2) path accepts
+
+}  // namespace cpk

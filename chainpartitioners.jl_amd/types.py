@@ -47,7 +47,7 @@ class SparseMatrixCSC:
     (CSR row pointer == colptr, CSR column index == rowval of the transpose).
     """
 
-    __slots__ = ("m", "n", "colptr", "rowval")
+    __slots__ = ("m", "n", "colptr", "rowval", "__weakref__")
 
     def __init__(self, m, n, colptr, rowval):
         self.m = int(m)

@@ -1,0 +1,125 @@
+/*
+ * chainpart.h -- C ABI of libchainpart.so, the MI355X (gfx950) engine for the contiguous
+ * partitioning hot path of ChainPartitioners.jl.
+ *
+ * The reference has no FFI layer (it is pure Julia; the boundary is multiple dispatch).
+ * These are the entry points a `ccall` shim binds to replace the reference methods named
+ * beside each declaration (paths under /root/reference/src).  INTEGRATION.md shows the shim.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all index VALUES 1-based exactly as Julia stores them;
+ *     arrays are caller-owned host memory unless the name says _device;
+ *   - every function returns a CP_* status (chainpart_types.h); cp_last_error() gives text;
+ *   - calls are synchronous (return after the stream is idle); handles are opaque,
+ *     single-owner, not thread-safe, freed by the matching *_destroy;
+ *   - there is NO CPU fallback: without a HIP device every compute entry returns CP_EHIP.
+ */
+#ifndef CHAINPART_H
+#define CHAINPART_H
+
+#include "chainpart_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cp_csr_s *cp_csr_t;        /* device-resident sparsity pattern + link arrays */
+typedef struct cp_count_s *cp_count_t;    /* device-resident counting structure */
+
+const char *cp_last_error(void);
+int32_t cp_version(void);
+/* number of visible HIP devices (0 if none); does not initialise a context */
+int32_t cp_device_count(void);
+
+/* ---- residency of A.colptr / A.rowval in HBM (SparseMatrixCSC fields; the reference reads
+ * them in every oracle constructor, e.g. SparseColorArrays.jl:101-118) ---- */
+int32_t cp_csr_create(int64_t m, int64_t n, int64_t N, const int64_t *colptr, const int64_t *rowval,
+                      int32_t device, cp_csr_t *out);
+/* same, but colptr/rowval already live in device memory (1-based int64, as Julia would upload them) */
+int32_t cp_csr_create_device(int64_t m, int64_t n, int64_t N, const int64_t *colptr_device,
+                             const int64_t *rowval_device, int32_t device, cp_csr_t *out);
+int32_t cp_csr_destroy(cp_csr_t csr);
+/* drop cached derived structures (link arrays, counters) so the next call rebuilds them:
+ * lets a benchmark time "one partition_stripe call including oracle construction" */
+int32_t cp_csr_reset_cache(cp_csr_t csr);
+
+/* ---- counting structures ----
+ * dominancecount(hint, A)   SparsePrefixMatrices.jl:438-458   kind CP_COUNT_DOM : C[i,j]
+ * netcount(hint, A)         SparseColorArrays.jl:57-58,101-125 kind CP_COUNT_NET : net[j,j']
+ * selfnetcount(hint, A)     SparseColorArrays.jl:165-229       kind CP_COUNT_SELFNET
+ * One exact device structure (wavelet bit-vectors) serves every hint: query results are
+ * integers independent of the structure. */
+#define CP_COUNT_DOM     0
+#define CP_COUNT_NET     1
+#define CP_COUNT_SELFNET 2
+int32_t cp_count_build(cp_csr_t csr, int32_t kind, int32_t hint, cp_count_t *out);
+int32_t cp_count_query(cp_count_t h, int64_t nq, const int64_t *a, const int64_t *b, int64_t *out);
+int32_t cp_count_destroy(cp_count_t h);
+/* the NetCount link array idx'[q] = (n+1) - hst[i] (SparseColorArrays.jl:106-113), for tests */
+int32_t cp_link_array(cp_csr_t csr, int64_t *out /* N */);
+
+/* partwise(A, Pi) PartwiseCounts.jl:1-60 */
+int32_t cp_partwise(cp_csr_t csr, int64_t K, const int64_t *asg, int64_t *nprime_out,
+                    int64_t *pios_out /* K+1 */, int64_t *prm_out /* <= N */,
+                    int64_t *pos_out /* <= N+1 */, int64_t *idx_out /* N */);
+
+/* ---- cost oracles ----
+ * ocl(j, j', k...) for a batch  (WorkCosts.jl:30-35, ConnectivityCosts.jl:58-64,
+ * HyperedgeCutCosts.jl:44-51, BlockCosts.jl:66-142); k may be NULL */
+int32_t cp_oracle_eval(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint,
+                       int64_t nq, const int64_t *j, const int64_t *jp, const int64_t *k,
+                       int64_t *out_i64, double *out_f64);
+/* bound_stripe(A, K, mdl)  WorkCosts.jl:37-51, ConnectivityCosts.jl:22-35 */
+int32_t cp_bound_stripe(cp_csr_t csr, int64_t K, const cp_model_t *model,
+                        int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);
+/* total_value / bottleneck_value  Costs.jl:26-66 */
+int32_t cp_objective(cp_csr_t csr, int64_t K, const int64_t *spl, const cp_model_t *model,
+                     const cp_rowpart_t *Pi, int32_t combine, int64_t *out_i64, double *out_f64);
+
+/* ---- partitioners ---- */
+/* partition_stripe(A, K, Dynamic{Total,Bottleneck}{Splitter,Chunker}(f | ConstrainedCost(f,w,w_max)), [Pi])
+ * DynamicSplitter.jl:15-50 (order SPLITTER), :52-87 (order CHUNKER), :206-314 (constrained);
+ * Reference{Total,Bottleneck}Splitter (ReferenceSplitter.jl:1-13) are the same entry. */
+int32_t cp_partition_dynamic(cp_csr_t csr, int64_t K, int32_t combine, int32_t order,
+                             const cp_model_t *model, const cp_rowpart_t *Pi,
+                             const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                             int64_t *spl_out /* K+1 */);
+/* pack_stripe(A, DynamicTotalChunker(f | ConstrainedCost(f,w,w_max)), [Pi])  DynamicChunker.jl:15-75 */
+int32_t cp_pack_dynamic(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi,
+                        const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                        int64_t *spl_out /* n+1 */, int64_t *K_out);
+/* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))  BisectCostBottleneckSplitter.jl:6-127 */
+int32_t cp_partition_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
+                                 int32_t flip, int64_t *spl_out /* K+1 */);
+/* pack_stripe(A, ConvexTotalChunker(..), [Pi]) / partition_stripe(A, K, ConvexTotalSplitter(..), [Pi])
+ * ConvexTotalChunker.jl:9-265 */
+int32_t cp_pack_convex(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi,
+                       const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                       int64_t *spl_out /* n+1 */, int64_t *K_out);
+int32_t cp_partition_convex(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi,
+                            const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                            int64_t *spl_out /* K+1 */);
+/* EquiSplitter / EquiChunker  EquiPartitioner.jl:3-22 (closed forms, host arithmetic) */
+int32_t cp_partition_equi(int64_t n, int64_t K, int64_t *spl_out /* K+1 */);
+int32_t cp_pack_equi(int64_t n, int64_t w, int64_t *spl_out /* cld(n,w)+1 */, int64_t *K_out);
+
+/* full (n+1) x K tables of the splitter-order DP, column-major like the reference's cst/ptr
+ * (DynamicSplitter.jl:23-24), for table-level parity tests.  Layer K holds row n+1 only. */
+int32_t cp_dynamic_tables(cp_csr_t csr, int64_t K, int32_t combine, const cp_model_t *model,
+                          const cp_rowpart_t *Pi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
+
+/* ---- execution control / measurement ---- */
+/* run subsequent launches of this csr on an existing hipStream_t (e.g. torch's current stream) */
+int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
+/* force the general O(K n^2) device DP even where the O(K n log^2 n) path applies (tests) */
+int32_t cp_set_option(const char *name, int64_t value);
+/* built-in per-kernel HIP-event timing of the named hot kernels on the launch stream */
+int32_t cp_prof_enable(int32_t on);
+int32_t cp_prof_reset(void);
+/* slot-wise totals: name, launches, total ms, algorithmic bytes; returns number of slots */
+int32_t cp_prof_get(int32_t slot, const char **name, int64_t *launches, double *total_ms, double *alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

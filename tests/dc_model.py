@@ -1,0 +1,85 @@
+"""Executable specification (numpy, small n) of the device algorithm for one layer of the
+total-cost splitter DP -- the "Fenwick rectangles + monotone divide-and-conquer + staircase
+path prefix sums" scheme of DESIGN.md section 4.  Used by the CPU tests to prove that the scheme
+reproduces the literal DP tables of the oracle (values AND argmins, ties -> largest j), and by
+the GPU tests as a readable statement of what the kernels in csrc/dp_total.hip compute.
+
+All indices here are 0-based boundary positions: p = j-1, r = j'-1, part = columns [p, r).
+"""
+import numpy as np
+
+
+def link_arrays(A):
+    """prev[q] / next[q]: previous / next column holding the same row (0-based; -1 / n if none)."""
+    n, N = A.n, A.nnz
+    cols = np.repeat(np.arange(n), np.diff(A.colptr))
+    rows = A.rowval - 1
+    prev = np.full(N, -1, dtype=np.int64)
+    nxt = np.full(N, n, dtype=np.int64)
+    last = {}
+    for q in range(N):
+        i = rows[q]
+        if i in last:
+            prev[q] = cols[last[i]]
+            nxt[last[i]] = cols[q]
+        last[i] = q
+    return prev, nxt
+
+
+def layer_total(A, Wprev, fcost, prev, nxt):
+    """Return (cst[r], ptr[r]) for r in 0..n:  min over p<=r of Wprev[p] + fcost(p, r, nets(p,r)),
+    ties -> largest p.  fcost(p, r, nn) is the model applied to (r-p, pins, nn)."""
+    n = A.n
+    pos = A.colptr - 1
+    nb = max(1, int(n).bit_length())
+    opt = np.full((n + 1, nb), -1, dtype=np.int64)
+    nnopt = np.zeros((n + 1, nb), dtype=np.int64)
+    val = np.full((n + 1, nb), np.inf)
+
+    def right_delta(c, thr):      # add column c on the right of a part starting at thr
+        return int(np.sum(prev[pos[c]:pos[c + 1]] < thr))
+
+    def left_delta(p, r):         # add column p on the left of a part ending before r
+        return int(np.sum(nxt[pos[p]:pos[p + 1]] >= r))
+
+    def run_task(r, b, B, a, S0, cols_right, virtual):
+        nn = S0
+        best = None
+        for c in cols_right:
+            nn += right_delta(c, B)
+        if not virtual:
+            best = (Wprev[B] + fcost(B, r, nn), B, nn)
+        for p in range(B - 1, a - 1, -1):
+            nn += left_delta(p, r)
+            v = Wprev[p] + fcost(p, r, nn)
+            if best is None or v < best[0]:        # strict: ties keep the larger p
+                best = (v, p, nn)
+        val[r, b], opt[r, b], nnopt[r, b] = best
+
+    # round A: rho == 0 rows of every rectangle
+    for r in range(1, n + 1):
+        b = (r & -r).bit_length() - 1
+        run_task(r, b, r, r - (1 << b), 0, [], True)
+    # rounds tau = high .. 0
+    for tau in range(nb - 1, -1, -1):
+        for r in range(1 << tau, n + 1, 1 << (tau + 1)):      # ctz(r) == tau
+            for b in range(tau + 1, nb):
+                if not (r >> b) & 1:
+                    continue
+                rb = (r >> b) << b
+                B0 = rb - (1 << b)
+                rL = r - (1 << tau)
+                rR = r + (1 << tau)
+                B = opt[rL, b]
+                S0 = nnopt[rL, b]
+                a = opt[rR, b] if (rR - rb) < (1 << b) and rR <= n else B0
+                run_task(r, b, B, a, S0, range(rL, r), False)
+    cst = np.zeros(n + 1, dtype=object)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    for r in range(n + 1):
+        bv, bp = Wprev[r] + fcost(r, r, 0), r
+        for b in range(nb):
+            if (r >> b) & 1 and val[r, b] < bv:
+                bv, bp = val[r, b], opt[r, b]
+        cst[r], ptr[r] = bv, bp
+    return cst, ptr

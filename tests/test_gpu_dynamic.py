@@ -1,0 +1,100 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bit-exact split indices and bit-exact DP tables (values and argmins, ties included)."""
+import numpy as np
+import pytest
+
+from util import cp, sprand, golden_matrices, suitesparse_shaped, banded
+
+pytestmark = pytest.mark.gpu
+
+
+def mats():
+    rng = np.random.default_rng(0xDEADBEEF)
+    out = [sprand(m, n, p, rng) for (m, n, p) in [(1, 1, 0.5), (3, 2, 0.5), (5, 7, 0.4), (8, 16, 0.3), (10, 23, 0.2),
+                                                  (6, 33, 0.3), (20, 40, 0.1), (3, 12, 0.6), (40, 100, 0.05), (9, 64, 0.2),
+                                                  (9, 65, 0.2), (9, 63, 0.2), (4, 8, 0.0)]]
+    out += list(golden_matrices().values())
+    out += [suitesparse_shaped(1000, 6, 3), banded(777, 4, 0.5, 9)]
+    return out
+
+
+MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100),
+          cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0), cp.AffineConnectivityModel(2, -3, 1, 3),
+          cp.AffineWorkModel(0, 10, 1)]
+
+
+def test_link_array_matches_reference_sweep(hip, orc):
+    for A in mats():
+        assert np.array_equal(hip.link_array(A), orc.link_array(A))
+
+
+@pytest.mark.parametrize("mi", range(len(MODELS)))
+def test_total_splitter_tables_bit_exact(hip, orc, mi):
+    mdl = MODELS[mi]
+    for A in mats():
+        for K in (1, 2, 5):
+            mm = mdl.marshal()
+            rc1, p1, c1 = hip.dynamic_tables(A, K, 0, mm, None)
+            rc2, p2, c2 = orc.dynamic_tables(A, K, 0, mm, None)
+            assert rc1 == 0 and rc2 == 0, hip.last_error()
+            assert np.array_equal(p1, p2), (A, K, mi)
+            assert np.array_equal(c1, c2), (A, K, mi)
+            got = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)
+            want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=orc)
+            assert got == want
+            got2 = cp.partition_stripe(A, K, cp.DynamicTotalChunker(mdl), backend=hip)
+            assert got2 == want
+
+
+def test_fast_path_equals_general_sweep(hip, orc):
+    """The O(n log^2 n) scheme and the literal O(n^2) device sweep agree with the oracle on a mid-size input."""
+    A = suitesparse_shaped(3000, 8, 11)
+    for mdl in (cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+        K = 6
+        want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=orc)
+        fast = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)
+        hip.set_option("force_brute", 1)
+        try:
+            brute = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)
+        finally:
+            hip.set_option("force_brute", 0)
+        assert fast == want and brute == want
+        assert cp.total_value(A, fast, mdl, backend=hip) == cp.total_value(A, want, mdl, backend=orc)
+
+
+@pytest.mark.parametrize("g", ["sum", "max"])
+def test_general_sweep_all_models(hip, orc, g):
+    """Bottleneck objective, hyperedge cut, per-part alpha[k], decreasing costs: general device sweep."""
+    rng = np.random.default_rng(5)
+    ms = [sprand(8, 16, 0.3, rng), sprand(20, 40, 0.1, rng), golden_matrices()["LPnetlib/lpi_itest6"],
+          golden_matrices()["Pajek/GD99_c"], suitesparse_shaped(300, 5, 2)]
+    for A in ms:
+        for K in (1, 2, 3, 4, 8):
+            base = 1 + A.nnz + 3 * A.n + 3 * A.m
+            models = [cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineWorkModel(0, 10, 1),
+                      cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), cp.AffineHyperedgeCutModel(0, 1, 1, 1, 3),
+                      cp.AffineHyperedgeCutModel(0, 0, 0, 1, 0),
+                      cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=rng.integers(1, 11, K).tolist()),
+                      cp.AffineConnectivityModel(0, -3, -1, -3, alpha_k=(base + rng.integers(1, 11, K)).tolist()),
+                      cp.AffineConnectivityModel(-0.5, 0.25, 0.0, 1.5)]
+            for mdl in models:
+                meth = (cp.DynamicTotalSplitter if g == "sum" else cp.DynamicBottleneckSplitter)(mdl)
+                got = cp.partition_stripe(A, K, meth, backend=hip)
+                want = cp.partition_stripe(A, K, meth, backend=orc)
+                assert got == want, (A, K, mdl.kind, g)
+                f = cp.total_value if g == "sum" else cp.bottleneck_value
+                a, b = f(A, got, mdl, backend=hip), f(A, want, mdl, backend=orc)
+                assert a == b or abs(a - b) <= 1e-12 * abs(b)        # Float64 totals: 1e-12 relative
+
+
+def test_objective_and_bounds(hip, orc):
+    rng = np.random.default_rng(8)
+    for A in [sprand(20, 40, 0.1, rng), golden_matrices()["HB/can_292"]]:
+        for K in (1, 3, 8):
+            Phi = cp.partition_stripe(A, K, cp.EquiSplitter())
+            for mdl in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100),
+                        cp.AffineHyperedgeCutModel(0, 0, 0, 1, 1), cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w)):
+                for f in (cp.total_value, cp.bottleneck_value):
+                    assert f(A, Phi, mdl, backend=hip) == f(A, Phi, mdl, backend=orc)
+            for mdl in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+                assert cp.bound_stripe(A, K, mdl, backend=hip) == cp.bound_stripe(A, K, mdl, backend=orc)
