@@ -11,10 +11,10 @@ namespace cpk {
 
 thread_local std::string g_last_error;
 ProfSlot g_prof[PROF_NSLOTS] = {
-    {"dp_expand_steps", 0, 0, 0}, {"dp_eval_candidates", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
+    {"dp_lpass", 0, 0, 0}, {"dp_open_segments", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
     {"scan", 0, 0, 0}, {"dp_tile_carry", 0, 0, 0}, {"dp_span_fix", 0, 0, 0}, {"dp_combine", 0, 0, 0},
     {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
-    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}};
+    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}};
 bool g_prof_on = false;
 std::vector<ProfPending> g_prof_pending;
 std::vector<hipEvent_t> g_event_pool;
@@ -202,7 +202,7 @@ void ensure_links(cp_csr_s *A)
     int64_t N = A->N, n = A->n, m = A->m;
     size_t Na = (size_t)(N > 0 ? N : 1);
     ProfScope ps(PROF_LINKS, s, 8.0 * (double)N + 8.0 * (double)(n + 1));
-    A->col.alloc(Na); A->prev.alloc(Na); A->next.alloc(Na);
+    A->col.alloc(Na); A->prev.alloc(Na + 8); A->next.alloc(Na + 8);     // +8: 16-byte vector loads may over-read the tail
     A->rfirst.alloc((size_t)(m > 0 ? m : 1)); A->rlast.alloc((size_t)(m > 0 ? m : 1));
     A->tpos.alloc((size_t)m + 1); A->tq.alloc(Na);
     CP_HIP(hipMemsetAsync(A->rfirst.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));

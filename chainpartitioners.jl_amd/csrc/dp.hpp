@@ -18,6 +18,7 @@ void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combin
                     int32_t *ptr_out, int64_t r_lo, int64_t r_hi);
 
 extern int64_t g_opt_force_brute;      // cp_set_option("force_brute", 1)
-extern int64_t g_opt_brute_max_n;      // largest n the O(n^2) path accepts
+extern int64_t g_opt_brute_max_n;
+extern int64_t g_opt_dbg;            // timing experiments only (cp_set_option("dbg", mask)); results are wrong when non-zero      // largest n the O(n^2) path accepts
 
 }  // namespace cpk

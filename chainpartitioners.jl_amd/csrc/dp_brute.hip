@@ -18,6 +18,7 @@ namespace cpk {
 
 int64_t g_opt_force_brute = 0;
 int64_t g_opt_brute_max_n = 200000;
+int64_t g_opt_dbg = 0;
 
 template <typename TC>
 __global__ void __launch_bounds__(256) k_brute_layer(int64_t n, int64_t r_lo, int64_t r_hi, const int64_t *__restrict__ pos,

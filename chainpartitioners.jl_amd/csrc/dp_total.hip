@@ -11,22 +11,25 @@
 //    W[p] + f(p,r) is inverse-Monge for the eligible models (coverage counts are submodular), so
 //    the RIGHTMOST row argmin is non-increasing in r: a monotone divide and conquer applies.
 //  * rows are processed in rounds by tau = ctz(r) (high to low) after a first round for the rows
-//    with r == r_b; a row's candidate range is bounded by the argmins of its two tree neighbours.
-//  * nets(p,r) along the staircase path anchor -> (B,r) -> (a,r) is a prefix sum of per-column
-//    steps: adding column c on the right of a part starting at B adds #{q in c : prev[q] < B};
-//    adding column p on the left of a part ending before r adds #{q in p : next[q] >= r}.
-//    All steps of all rows of a round are flattened into one array, counted in a streaming pass over
-//    the link arrays (k_expand), segment-scanned (tile scan + carry), evaluated and arg-min reduced
-//    (k_eval, k_fix).
+//    with r == r_b; a row's candidate range [a, B] is bounded by the argmins of its two tree neighbours
+//    r - 2^tau (gives B and the anchor count) and r + 2^tau (gives a).
+//  * nets(p,r) along the staircase path anchor (B, r-2^tau) -> (B,r) -> (a,r):
+//      right part: columns [r-2^tau, r) join a part starting at B: + #{q : prev[q] < B}.  Only the TOTAL is
+//        needed, and the same columns serve every set bit b of r (different thresholds B_b): one row-major
+//        reduction pass per round (k_rpass_*), N/2 link entries per round.
+//      left part: columns p = B-1 .. a join a part ending before r: + #{q in p : next[q] >= r}, one
+//        candidate per column.  All left steps of a round are flattened (1 + B - a elements per row-task),
+//        streamed wave-cooperatively (coalesced 64-entry chunks, ballot/popcount per column), segment-scanned
+//        with wave shuffles, evaluated and arg-min reduced in the same kernel (k_lpass).  Tasks that span
+//        several 256-step tiles finish in k_open / k_fix.
 #include "csr.hpp"
 #include "model.hpp"
 #include "dp.hpp"
 
 namespace cpk {
 
-constexpr int TILE_T = 256;
-constexpr int TILE_I = 4;
-constexpr int TILE = TILE_T * TILE_I;
+constexpr int LT = 256;          // steps per tile (one wave owns one tile)
+constexpr int NBMAX = 31;        // bit planes (n < 2^30)
 
 struct RoundDesc {
     int32_t isA, tau, nbits, _pad;
@@ -46,8 +49,82 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
     b = bb;
 }
 
+// ------------------------------------------------------------------ right part: row-major threshold counts
+// cr[b][r] = #{q in columns [r-2^tau, r) : prev[q] < opt[b][r-2^tau]} for every set bit b > tau of r.
+// Small ranges: one lane per row (tau <= 3).
+__global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, const int64_t *__restrict__ pos,
+                                                     const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
+                                                     int32_t *__restrict__ cr)
+{
+    int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r = ((u << 1) | 1) << tau;
+    if (r > n) return;
+    int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
+    int32_t thr[NBMAX], cnt[NBMAX];
+#pragma unroll
+    for (int b = 0; b < NBMAX; b++) {
+        bool on = b > tau && b < nbits && ((r >> b) & 1);
+        thr[b] = on ? opt[(int64_t)b * n1 + rL] : INT32_MIN;
+        cnt[b] = 0;
+    }
+    int64_t q0 = pos[rL], q1 = pos[r];
+    for (int64_t q = q0; q < q1; q++) {
+        int32_t v = prev[q];
+#pragma unroll
+        for (int b = 0; b < NBMAX; b++) cnt[b] += (v < thr[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NBMAX; b++)
+        if (b > tau && b < nbits && ((r >> b) & 1)) cr[(int64_t)b * n1 + r] = cnt[b];
+}
+
+// Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
+__global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t nrows, int chunks_per_row, int ch_cols,
+                                                    const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
+                                                    const int32_t *__restrict__ opt, int32_t *__restrict__ cr)
+{
+    int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    int64_t u = w / chunks_per_row;
+    int ck = (int)(w - u * chunks_per_row);
+    if (u >= nrows) return;
+    int64_t r = ((u << 1) | 1) << tau;
+    if (r > n) return;
+    int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
+    int64_t c0 = rL + (int64_t)ck * ch_cols, c1 = c0 + ch_cols;
+    if (c1 > r) c1 = r;
+    int32_t thr[NBMAX], cnt[NBMAX];
+#pragma unroll
+    for (int b = 0; b < NBMAX; b++) {
+        bool on = b > tau && b < nbits && ((r >> b) & 1);
+        thr[b] = on ? opt[(int64_t)b * n1 + rL] : INT32_MIN;       // wave-uniform address
+        cnt[b] = 0;
+    }
+    int64_t q0 = pos[c0], q1 = pos[c1];
+    for (int64_t q = q0 + lane; q < q1; q += 64) {
+        int32_t v = prev[q];
+#pragma unroll
+        for (int b = 0; b < NBMAX; b++) cnt[b] += (v < thr[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NBMAX; b++) {
+        bool on = b > tau && b < nbits && ((r >> b) & 1);          // wave-uniform
+        if (on) {
+            int32_t c = cnt[b];
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+            if (lane == 0) {
+                if (chunks_per_row == 1) cr[(int64_t)b * n1 + r] = c;
+                else atomicAdd(&cr[(int64_t)b * n1 + r], c);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ task setup
+// element 0 of a task is the candidate p = B (its count = anchor + right part); elements i >= 1 are the
+// left steps p = B - i.  Round A: B = r is virtual (not a candidate), anchor 0.
 __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
+                                               int32_t *__restrict__ cr, int zero_cr_only,
                                                int32_t *__restrict__ tB, int32_t *__restrict__ tS0, int32_t *__restrict__ tr,
                                                uint8_t *__restrict__ tb, int32_t *__restrict__ len)
 {
@@ -56,176 +133,23 @@ __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__res
     int64_t r; int b;
     decode_task(R, t, r, b);
     int64_t n1 = R.n + 1;
-    int64_t B, a, S0, nR;
+    if (zero_cr_only) { cr[(int64_t)b * n1 + r] = 0; return; }
+    int64_t B, a, S0;
     if (R.isA) {
-        B = r; a = r - ((int64_t)1 << b); S0 = 0; nR = 0;
+        B = r; a = r - ((int64_t)1 << b); S0 = 0;
     } else {
         int64_t rb = (r >> b) << b;
         int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
         B = opt[(int64_t)b * n1 + rL];
-        S0 = nnopt[(int64_t)b * n1 + rL];
+        S0 = (int64_t)nnopt[(int64_t)b * n1 + rL] + cr[(int64_t)b * n1 + r];
         a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
-        nR = (int64_t)1 << R.tau;
         if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
     }
     tB[t] = (int32_t)B; tS0[t] = (int32_t)S0; tr[t] = (int32_t)r; tb[t] = (uint8_t)b;
-    len[t] = (int32_t)(nR + (B - a));
+    len[t] = (int32_t)(1 + (B - a));
 }
 
-// ------------------------------------------------------------------ tile helpers
-struct TileTasks {
-    int64_t t0;          // first task overlapping the tile
-    int32_t cnt;         // number of task offsets loaded (tasks t0 .. t0+cnt-1 start at s_off[0..cnt-1])
-};
-
-// loads the offsets of the tasks overlapping [tile_start, tile_start+TILE) into s_off (absolute int64)
-__device__ __forceinline__ void load_tile_tasks(const int64_t *__restrict__ offs, int64_t ntask, int64_t tile_start,
-                                                int64_t *s_off, int64_t *s_t0, int32_t *s_cnt)
-{
-    if (threadIdx.x == 0) {
-        int64_t lo = 0, hi = ntask;         // last t with offs[t] <= tile_start  (offs[0] = 0)
-        while (hi - lo > 1) {
-            int64_t mid = (lo + hi) >> 1;
-            if (offs[mid] <= tile_start) lo = mid; else hi = mid;
-        }
-        *s_t0 = lo;
-        int64_t c = ntask - lo;             // every task has len >= 1, so at most TILE tasks start inside the tile
-        *s_cnt = (int32_t)(c > TILE + 1 ? TILE + 1 : c);
-    }
-    __syncthreads();
-    int64_t t0 = *s_t0;
-    int32_t cnt = *s_cnt;
-    for (int i = threadIdx.x; i < cnt; i += TILE_T) s_off[i] = offs[t0 + i];
-    __syncthreads();
-}
-
-// local task index: last i in [0,cnt) with s_off[i] <= e
-__device__ __forceinline__ int find_local(const int64_t *s_off, int32_t cnt, int64_t e)
-{
-    int lo = 0, hi = cnt;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (s_off[mid] <= e) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// ------------------------------------------------------------------ expand: per-step column counts + tile-local segmented scan
-// loc[e] = sum of the step counts of e's task from max(task start, tile start) through e.
-__global__ void __launch_bounds__(TILE_T) k_expand(RoundDesc R, int64_t T, const int64_t *__restrict__ offs,
-                                                   const int32_t *__restrict__ tB, const int32_t *__restrict__ tr,
-                                                   const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
-                                                   const int32_t *__restrict__ next,
-                                                   int32_t *__restrict__ loc, int32_t *__restrict__ tileF, int32_t *__restrict__ tileS)
-{
-    __shared__ int64_t s_off[TILE + 2];
-    __shared__ int64_t s_t0;
-    __shared__ int32_t s_cnt;
-    __shared__ int32_t s_F[TILE_T], s_S[TILE_T];
-    int64_t tile_start = (int64_t)blockIdx.x * TILE;
-    load_tile_tasks(offs, R.ntask, tile_start, s_off, &s_t0, &s_cnt);
-    int64_t t0 = s_t0;
-    int32_t cnt = s_cnt;
-    int64_t nR = R.isA ? 0 : ((int64_t)1 << R.tau);
-
-    int32_t d[TILE_I];
-    bool h[TILE_I];
-    int64_t e0 = tile_start + (int64_t)threadIdx.x * TILE_I;
-#pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        int64_t e = e0 + k;
-        d[k] = 0; h[k] = true;
-        if (e < T) {
-            int li = find_local(s_off, cnt, e);
-            int64_t t = t0 + li;
-            int64_t i = e - s_off[li];
-            h[k] = (i == 0);
-            int64_t B = tB[t], r = tr[t];
-            int32_t c = 0;
-            if (i < nR) {                       // right step: column (r - 2^tau + i) joins a part that starts at B
-                int64_t col = r - nR + i;
-                int64_t q0 = pos[col], q1 = pos[col + 1];
-                int32_t thr = (int32_t)B;
-                for (int64_t q = q0; q < q1; q++) c += (prev[q] < thr);
-            } else {                            // left step: column p joins a part that ends before r
-                int64_t p = B - 1 - (i - nR);
-                int64_t q0 = pos[p], q1 = pos[p + 1];
-                int32_t thr = (int32_t)r;
-                for (int64_t q = q0; q < q1; q++) c += (next[q] >= thr);
-            }
-            d[k] = c;
-        }
-    }
-    // thread-local segmented inclusive scan
-    int32_t x[TILE_I];
-    int32_t run = 0;
-    bool anyh = false;
-    int firsth = TILE_I;
-#pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        if (h[k]) { run = 0; if (!anyh) firsth = k; anyh = true; }
-        run += d[k];
-        x[k] = run;
-    }
-    s_F[threadIdx.x] = anyh; s_S[threadIdx.x] = run;
-    __syncthreads();
-    // block-level inclusive segmented scan of (F,S): (F1,S1)+(F2,S2) = (F1|F2, F2 ? S2 : S1+S2)
-    for (int o = 1; o < TILE_T; o <<= 1) {
-        int32_t f = 0, sv = 0;
-        bool take = threadIdx.x >= (unsigned)o;
-        if (take) { f = s_F[threadIdx.x - o]; sv = s_S[threadIdx.x - o]; }
-        __syncthreads();
-        if (take) {
-            int32_t mf = s_F[threadIdx.x], ms = s_S[threadIdx.x];
-            s_S[threadIdx.x] = mf ? ms : sv + ms;
-            s_F[threadIdx.x] = mf | f;
-        }
-        __syncthreads();
-    }
-    int32_t carry = threadIdx.x > 0 ? s_S[threadIdx.x - 1] : 0;
-#pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        int64_t e = e0 + k;
-        if (e < T) loc[e] = x[k] + (k < firsth ? carry : 0);
-    }
-    if (threadIdx.x == TILE_T - 1) { tileF[blockIdx.x] = s_F[TILE_T - 1]; tileS[blockIdx.x] = s_S[TILE_T - 1]; }
-}
-
-// ------------------------------------------------------------------ carry across tiles (single block)
-// carry[i] = sum of the counts of tile i's first segment that lie in earlier tiles (0 if tile i starts with a head;
-// a stale non-zero value there is harmless: k_eval applies the carry only to a segment that started earlier).
-__global__ void __launch_bounds__(1024) k_carry(const int32_t *__restrict__ tileF, const int32_t *__restrict__ tileS,
-                                                int32_t *__restrict__ carry, int64_t ntile)
-{
-    __shared__ int32_t s_F[1024], s_S[1024];
-    int64_t chunk = (ntile + 1023) / 1024;
-    int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < ntile ? lo + chunk : ntile;
-    int32_t f = 0, sv = 0;
-    for (int64_t i = lo; i < hi; i++) {
-        if (tileF[i]) { f = 1; sv = tileS[i]; } else sv += tileS[i];
-    }
-    s_F[threadIdx.x] = f; s_S[threadIdx.x] = sv;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int32_t pf = 0, psv = 0;
-        bool take = threadIdx.x >= (unsigned)o;
-        if (take) { pf = s_F[threadIdx.x - o]; psv = s_S[threadIdx.x - o]; }
-        __syncthreads();
-        if (take) {
-            int32_t mf = s_F[threadIdx.x], ms = s_S[threadIdx.x];
-            s_S[threadIdx.x] = mf ? ms : psv + ms;
-            s_F[threadIdx.x] = mf | pf;
-        }
-        __syncthreads();
-    }
-    int32_t run = threadIdx.x > 0 ? s_S[threadIdx.x - 1] : 0;     // inclusive value of everything before lo
-    for (int64_t i = lo; i < hi; i++) {
-        carry[i] = run;
-        if (tileF[i]) run = tileS[i]; else run += tileS[i];
-    }
-}
-
-// ------------------------------------------------------------------ evaluate candidates + segmented arg-min
+// ------------------------------------------------------------------ wave-level segmented scans (64 lanes)
 template <typename TC>
 struct Best { TC v; int32_t p; int32_t nn; };
 
@@ -237,110 +161,267 @@ __device__ __forceinline__ Best<TC> better(const Best<TC> &a, const Best<TC> &b)
     return (b.v < a.v) ? b : a;
 }
 
-template <typename TC>
-__global__ void __launch_bounds__(TILE_T) k_eval(RoundDesc R, int64_t T, const int64_t *__restrict__ offs,
-                                                 const int32_t *__restrict__ tB, const int32_t *__restrict__ tS0,
-                                                 const int32_t *__restrict__ tr, const uint8_t *__restrict__ tb,
-                                                 const int64_t *__restrict__ pos, const int32_t *__restrict__ loc,
-                                                 const int32_t *__restrict__ carry, const TC *__restrict__ W,
-                                                 DevModel<TC> M, TC alpha,
-                                                 int32_t *__restrict__ opt, int32_t *__restrict__ nnopt,
-                                                 Best<TC> *__restrict__ partL, Best<TC> *__restrict__ partR,
-                                                 int64_t *__restrict__ taskR)
+__device__ __forceinline__ int64_t shfl_up64(int64_t v, int o)
 {
-    __shared__ int64_t s_off[TILE + 2];
-    __shared__ int64_t s_t0;
-    __shared__ int32_t s_cnt;
-    __shared__ int32_t s_F[TILE_T];
-    __shared__ Best<TC> s_B[TILE_T];
-    int64_t tile_start = (int64_t)blockIdx.x * TILE;
-    load_tile_tasks(offs, R.ntask, tile_start, s_off, &s_t0, &s_cnt);
-    int64_t t0 = s_t0;
-    int32_t cnt = s_cnt;
-    int64_t nR = R.isA ? 0 : ((int64_t)1 << R.tau);
-    int32_t cin = carry[blockIdx.x];
-    int64_t n1 = R.n + 1;
+    int lo = __shfl_up((int)(v & 0xffffffffll), o), hi = __shfl_up((int)(v >> 32), o);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ double shfl_up64(double v, int o) { return __longlong_as_double((long long)shfl_up64((int64_t)__double_as_longlong(v), o)); }
+__device__ __forceinline__ int64_t shfl64(int64_t v, int src)
+{
+    int lo = __shfl((int)(v & 0xffffffffll), src), hi = __shfl((int)(v >> 32), src);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ double shfl64(double v, int src) { return __longlong_as_double((long long)shfl64((int64_t)__double_as_longlong(v), src)); }
 
-    Best<TC> x[TILE_I];
-    bool h[TILE_I];
-    int64_t tsk[TILE_I];
-    int64_t e0 = tile_start + (int64_t)threadIdx.x * TILE_I;
+// inclusive segmented sum: v = sum from the last head at or before this lane (or lane 0), f = "a head lies in [0, lane]"
+__device__ __forceinline__ void wave_segsum(int32_t &v, int &f, int lane)
+{
 #pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        int64_t e = e0 + k;
-        x[k].p = -1; x[k].nn = 0; x[k].v = (TC)0; h[k] = true; tsk[k] = -1;
-        if (e < T) {
-            int li = find_local(s_off, cnt, e);
-            int64_t t = t0 + li;
-            tsk[k] = t;
-            int64_t toff = s_off[li];
-            int64_t i = e - toff;
-            h[k] = (i == 0);
-            int64_t B = tB[t], r = tr[t];
-            int64_t nn = (int64_t)tS0[t] + loc[e] + (toff < tile_start ? cin : 0);
-            int64_t p = -1;
-            if (i >= nR) p = B - 1 - (i - nR);
-            else if (i == nR - 1) p = B;
-            if (p >= 0) {
-                TC f = dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, (int64_t)0);
-                x[k].v = cadd(W[p], f);
-                x[k].p = (int32_t)p;
-                x[k].nn = (int32_t)nn;
-            }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        int32_t pv = __shfl_up(v, o);
+        int pf = __shfl_up(f, o);
+        if (lane >= o) { if (!f) v += pv; f |= pf; }
     }
-    // thread-local segmented inclusive "best so far"
-    Best<TC> run; run.p = -1; run.nn = 0; run.v = (TC)0;
-    bool anyh = false;
-    int firsth = TILE_I;
+}
+
+template <typename TC>
+__device__ __forceinline__ void wave_segmin(Best<TC> &x, int &f, int lane)
+{
 #pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        if (h[k]) { run.p = -1; if (!anyh) firsth = k; anyh = true; }
-        run = better(run, x[k]);
-        x[k] = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        Best<TC> p;
+        p.v = shfl_up64(x.v, o);
+        p.p = __shfl_up(x.p, o);
+        p.nn = __shfl_up(x.nn, o);
+        int pf = __shfl_up(f, o);
+        if (lane >= o) { if (!f) x = better(p, x); f |= pf; }
     }
-    s_F[threadIdx.x] = anyh; s_B[threadIdx.x] = run;
+}
+
+// ------------------------------------------------------------------ tile task table (one wave = one tile)
+// first task overlapping each tile: last t with offs[t] <= tile*LT (one thread per tile; offs[0] = 0)
+__global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ offs, int64_t ntask, int64_t ntile, int64_t *__restrict__ tile_t0)
+{
+    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntile) return;
+    int64_t tile_start = tile * LT;
+    int64_t lo = 0, hi = ntask;
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= tile_start) lo = mid; else hi = mid;
+    }
+    tile_t0[tile] = lo;
+}
+
+// loads the offsets of the tasks overlapping the tile and a bitmap of the task heads inside it
+__device__ __forceinline__ void load_tile_tasks(const int64_t *__restrict__ offs, int64_t ntask, int64_t t0, int64_t tile_start,
+                                                bool active, int64_t *s_off, unsigned long long *s_hd, int lane, int &cnt)
+{
+    int64_t c = ntask - t0;                  // every task has len >= 1: at most LT tasks start inside the tile
+    cnt = active ? (int)(c > LT + 1 ? LT + 1 : c) : 0;
+    if (lane < LT / 64) s_hd[lane] = 0ull;
+    for (int i = lane; i < cnt; i += 64) {
+        int64_t o = offs[t0 + i];
+        s_off[i] = o;
+        int64_t rel = o - tile_start;
+        if (rel >= 0 && rel < LT) atomicOr(&s_hd[rel >> 6], 1ull << (rel & 63));
+    }
+}
+
+// ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
+template <typename TC>
+__global__ void __launch_bounds__(256) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ offs,
+                                               const int32_t *__restrict__ tB, const int32_t *__restrict__ tS0,
+                                               const int32_t *__restrict__ tr, const uint8_t *__restrict__ tb,
+                                               const int64_t *__restrict__ pos, const int32_t *__restrict__ next,
+                                               const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                               int32_t *__restrict__ opt, int32_t *__restrict__ nnopt,
+                                               int32_t *__restrict__ loc, int32_t *__restrict__ tileS,
+                                               Best<TC> *__restrict__ partR, int64_t *__restrict__ taskR,
+                                               const int64_t *__restrict__ tile_t0, int dbg)
+{
+    __shared__ int64_t s_off_all[4][LT + 2];
+    __shared__ unsigned long long s_hd_all[4][LT / 64];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int64_t tile_start = tile * LT;
+    bool active = tile_start < T;
+    int64_t *s_off = s_off_all[wave];
+    unsigned long long *s_hd = s_hd_all[wave];
+    int64_t t0 = active ? tile_t0[tile] : 0; int cnt;
+    load_tile_tasks(offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     __syncthreads();
-    for (int o = 1; o < TILE_T; o <<= 1) {
-        int32_t f = 0; Best<TC> pb; pb.p = -1; pb.nn = 0; pb.v = (TC)0;
-        bool take = threadIdx.x >= (unsigned)o;
-        if (take) { f = s_F[threadIdx.x - o]; pb = s_B[threadIdx.x - o]; }
-        __syncthreads();
-        if (take) {
-            int32_t mf = s_F[threadIdx.x];
-            Best<TC> mb = s_B[threadIdx.x];
-            s_B[threadIdx.x] = mf ? mb : better(pb, mb);
-            s_F[threadIdx.x] = mf | f;
-        }
-        __syncthreads();
-    }
-    Best<TC> cb; cb.p = -1; cb.nn = 0; cb.v = (TC)0;
-    if (threadIdx.x > 0) cb = s_B[threadIdx.x - 1];
-    int64_t tile_last = tile_start + TILE - 1;
+    if (!active) return;
+    // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
+    int head_at0 = (s_off[0] == tile_start) ? 1 : 0;
+    int hd_before = 0;                                  // heads in the groups already processed
+    int64_t n1 = R.n + 1;
+    int64_t tile_last = tile_start + LT - 1;
     if (tile_last > T - 1) tile_last = T - 1;
+
+    constexpr int NG = LT / 64;
+    int carryF = 0; int32_t carryS = 0;               // segmented-sum state across the groups of the tile
+    Best<TC> bcarry; bcarry.p = -1; bcarry.nn = 0; bcarry.v = (TC)0;
+    for (int g = 0; g < NG; g++) {
+        int64_t e = tile_start + g * 64 + lane;
+        bool valid = e <= tile_last;
+        int64_t t = 0, i = 0, r = 0, B = 0, p = -1, toff = 0, seg_last = -1, s = 0, en = 0, posr = 0;
+        int32_t s0 = 0; TC wp = (TC)0;
+        unsigned long long hmask = s_hd[g];
+        if (valid) {
+            int li = hd_before + __popcll(hmask & ((2ull << lane) - 1)) - head_at0;
+            t = t0 + li;
+            toff = s_off[li];
+            seg_last = ((li + 1 < cnt) ? s_off[li + 1] : offs[t + 1]) - 1;
+            i = e - toff;
+            r = tr[t]; B = tB[t]; s0 = tS0[t];
+            p = B - i;
+            if (i == 0) { s = en = pos[B]; }
+            else { s = pos[p]; en = pos[p + 1]; }
+            posr = pos[r];
+            wp = W[p];
+            if (i == 0 && R.isA) p = -1;              // round A: element 0 (p = r) is not a candidate
+        }
+        hd_before += __popcll(hmask);
+        int32_t thr = valid ? (int32_t)r : INT32_MAX;
+        // ---- cooperative streaming: a run = lanes whose nonzero ranges are adjacent and descending.
+        // The run's nonzeros [q_lo, q_hi) are read as aligned 16-byte-per-lane loads (1 KiB per wave instruction,
+        // two in flight); position x + 4*lane' + j sits in component j of lane'.
+        int64_t prev_s = shfl_up64(s, 1);
+        int prev_valid = __shfl_up((int)valid, 1);
+        bool cont = valid && lane > 0 && prev_valid && (en == prev_s);
+        unsigned long long heads = __ballot(valid && !cont);
+        unsigned long long vm = __ballot(valid);
+        int32_t d = 0;
+        while (heads) {
+            int h0 = __ffsll((long long)heads) - 1;
+            heads &= heads - 1;
+            int h1 = heads ? (__ffsll((long long)heads) - 1) : 64;
+            unsigned long long inrun = vm & (h1 == 64 ? ~0ull : ((1ull << h1) - 1)) & ~((1ull << h0) - 1);
+            int hl = 63 - __clzll((long long)inrun);      // last valid lane of the run
+            int64_t q_hi = shfl64(en, h0), q_lo = shfl64(s, hl);
+            bool mine = lane >= h0 && lane <= hl && en > s;
+            for (int64_t x = q_lo & ~(int64_t)3; x < q_hi && !(dbg & 4); x += 512) {
+                int4 v0 = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN), v1 = v0;
+                int64_t b0 = x + 4 * lane, b1 = b0 + 256;
+                if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(next + b0);     // next is padded by 4 entries
+                if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(next + b1);
 #pragma unroll
-    for (int k = 0; k < TILE_I; k++) {
-        int64_t e = e0 + k;
-        if (e >= T) continue;
-        Best<TC> res = (k < firsth) ? better(cb, x[k]) : x[k];
-        int64_t t = tsk[k];
-        int li = (int)(t - t0);
-        int64_t seg_start = s_off[li];
-        int64_t seg_last = ((li + 1 < cnt) ? s_off[li + 1] : offs[t + 1]) - 1;
-        bool head_in_tile = seg_start >= tile_start;
-        if (e == seg_last) {
-            if (head_in_tile) {
-                int64_t r = tr[t]; int b = tb[t];
-                opt[(int64_t)b * n1 + r] = res.p;
-                nnopt[(int64_t)b * n1 + r] = res.nn;
-            } else {
-                partL[blockIdx.x] = res;
+                for (int c = 0; c < 2; c++) {
+                    int64_t xc = x + c * 256;
+                    if (xc >= q_hi) break;                // wave-uniform
+                    int4 v = c ? v1 : v0;
+                    int64_t pb = xc + 4 * lane;           // position of component 0
+                    bool in0 = pb >= q_lo && pb < q_hi, in1 = pb + 1 >= q_lo && pb + 1 < q_hi;
+                    bool in2 = pb + 2 >= q_lo && pb + 2 < q_hi, in3 = pb + 3 >= q_lo && pb + 3 < q_hi;
+                    bool ov = mine && s < xc + 256 && en > xc;
+                    // this lane's column covers positions [a0, a1) of the block: lanes [lo_j, hi_j) of component j
+                    int a0 = ov ? (int)((s > xc ? s : xc) - xc) : 0, a1 = ov ? (int)((en < xc + 256 ? en : xc + 256) - xc) : 0;
+                    unsigned long long rem = __ballot(ov);
+                    while (rem) {                         // one pass per distinct threshold (= task) touching the block
+                        int l = __ffsll((long long)rem) - 1;
+                        int32_t thr_u = __shfl(thr, l);
+                        unsigned long long m0 = __ballot(in0 && v.x >= thr_u), m1 = __ballot(in1 && v.y >= thr_u);
+                        unsigned long long m2 = __ballot(in2 && v.z >= thr_u), m3 = __ballot(in3 && v.w >= thr_u);
+                        bool same = ov && thr == thr_u;
+                        if (same) {
+#define CP_CNT(mj, j)                                                                                   \
+    {                                                                                                   \
+        int lo_ = (a0 - (j) + 3) >> 2, hi_ = (a1 - (j) + 3) >> 2;                                       \
+        if (lo_ < 0) lo_ = 0;                                                                           \
+        if (hi_ > lo_) {                                                                                \
+            int w_ = hi_ - lo_;                                                                         \
+            unsigned long long mm_ = (w_ >= 64) ? ~0ull : (((1ull << w_) - 1) << lo_);                 \
+            d += __popcll((mj) & mm_);                                                                  \
+        }                                                                                               \
+    }
+                            CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
+#undef CP_CNT
+                        }
+                        rem &= ~__ballot(same);
+                    }
+                }
             }
-        } else if (e == tile_last) {
-            if (head_in_tile) { partR[blockIdx.x] = res; taskR[blockIdx.x] = t; }
-            else partL[blockIdx.x] = res;
+        }
+        // ---- segmented prefix of the step counts (restart at every task head)
+        int f = valid ? (i == 0) : 1;
+        int32_t x = d;
+        wave_segsum(x, f, lane);
+        if (!f) x += carryS;
+        int nf = __shfl(f, 63);
+        int32_t nS = __shfl(x, 63);
+        carryS = nS; carryF |= nf;
+        // ---- evaluate (only where the task head lies in this tile: the count is final)
+        bool head_in_tile = valid && toff >= tile_start;
+        Best<TC> bx; bx.p = -1; bx.nn = 0; bx.v = (TC)0;
+        if (head_in_tile && p >= 0) {
+            int64_t nn = (int64_t)s0 + x;
+            TC fv = dm_apply(M, alpha, r - p, posr - s, nn, (int64_t)0);     // s == pos[p] for every candidate
+            bx.v = cadd(wp, fv); bx.p = (int32_t)p; bx.nn = (int32_t)nn;
+        } else if (valid && !head_in_tile) {
+            loc[e] = x;                                 // count since the tile start; finished by k_open
+        }
+        int bf = valid ? (i == 0) : 1;
+        if (!(dbg & 2)) wave_segmin(bx, bf, lane);
+        if (!bf) bx = better(bcarry, bx);
+        {
+            Best<TC> nb; nb.v = shfl64(bx.v, 63); nb.p = __shfl(bx.p, 63); nb.nn = __shfl(bx.nn, 63);
+            bcarry = nb;
+        }
+        if (head_in_tile) {
+            if (e == seg_last) {
+                int b = tb[t];
+                opt[(int64_t)b * n1 + r] = bx.p;
+                nnopt[(int64_t)b * n1 + r] = bx.nn;
+            } else if (e == tile_last) {
+                partR[tile] = bx; taskR[tile] = t;
+            }
         }
     }
+    if (lane == 0) tileS[tile] = carryS;    // counts since the last head of the tile (or the whole tile)
+    (void)carryF;
+}
+
+// ------------------------------------------------------------------ open-left part of a tile (task started in an earlier tile)
+template <typename TC>
+__global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ offs,
+                                              const int32_t *__restrict__ tB, const int32_t *__restrict__ tS0,
+                                              const int32_t *__restrict__ tr, const int64_t *__restrict__ pos,
+                                              const int32_t *__restrict__ loc, const int64_t *__restrict__ tilePS,
+                                              const int64_t *__restrict__ tile_t0,
+                                              const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC> *__restrict__ partL)
+{
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= ntile) return;
+    int64_t tile_start = tile * LT;
+    int64_t t = tile_t0[tile];                          // task of the tile's first step
+    int64_t toff = offs[t];
+    if (toff >= tile_start) return;                     // tile starts with a head: nothing open on the left
+    int64_t last = offs[t + 1] - 1;
+    int64_t tile_last = tile_start + LT - 1;
+    if (tile_last > T - 1) tile_last = T - 1;
+    if (last > tile_last) last = tile_last;
+    int64_t r = tr[t], B = tB[t];
+    // counts of this task in earlier tiles: its head tile contributes "since the last head", every tile in
+    // between is covered entirely by the task: a range sum over the per-tile tails (tilePS = their prefix sums)
+    int64_t base = (int64_t)tS0[t] + (tilePS[tile] - tilePS[toff / LT]);
+    Best<TC> best; best.p = -1; best.nn = 0; best.v = (TC)0;
+    for (int64_t e = tile_start + lane; e <= last; e += 64) {
+        int64_t p = B - (e - toff);
+        int64_t nn = base + loc[e];
+        TC fv = dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, (int64_t)0);
+        Best<TC> c; c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn;
+        best = better(best, c);                         // a lane visits its steps in increasing e (decreasing p)
+    }
+    // wave arg-min; ties -> larger p
+    for (int o = 32; o > 0; o >>= 1) {
+        Best<TC> c; c.v = shfl64(best.v, (lane + o) & 63); c.p = __shfl(best.p, (lane + o) & 63); c.nn = __shfl(best.nn, (lane + o) & 63);
+        bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
+        if (lane + o < 64 && take) best = c;
+    }
+    if (lane == 0) partL[tile] = best;
 }
 
 // a task whose steps span several tiles: combine the head tile's partial with the partials of the tiles it covers
@@ -354,27 +435,25 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
     int64_t t = taskR[tile];
     if (t < 0) return;
     __shared__ Best<TC> s_B[256];
-    __shared__ int64_t s_K[256];
-    int64_t end_tile = (offs[t + 1] - 1) / TILE;
+    int64_t end_tile = (offs[t + 1] - 1) / LT;
     Best<TC> acc; acc.p = -1; acc.nn = 0; acc.v = (TC)0;
-    int64_t acck = INT64_MAX;
     for (int64_t k = tile + 1 + threadIdx.x; k <= end_tile; k += 256) {
-        Best<TC> c = partL[k];          // tiles are visited in increasing order by each thread: earlier wins ties
-        if (acc.p < 0 || (c.p >= 0 && c.v < acc.v)) { if (c.p >= 0) { acc = c; acck = k; } }
+        Best<TC> c = partL[k];
+        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+        if (take) acc = c;
     }
-    s_B[threadIdx.x] = acc; s_K[threadIdx.x] = acck;
+    s_B[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < (unsigned)o) {
             Best<TC> a = s_B[threadIdx.x], b = s_B[threadIdx.x + o];
-            int64_t ka = s_K[threadIdx.x], kb = s_K[threadIdx.x + o];
-            bool takeb = (a.p < 0) ? (b.p >= 0) : (b.p >= 0 && (b.v < a.v || (b.v == a.v && kb < ka)));
-            if (takeb) { s_B[threadIdx.x] = b; s_K[threadIdx.x] = kb; }
+            bool takeb = (a.p < 0) ? (b.p >= 0) : (b.p >= 0 && (b.v < a.v || (b.v == a.v && b.p > a.p)));
+            if (takeb) s_B[threadIdx.x] = b;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        Best<TC> res = better(partR[tile], s_B[0]);
+        Best<TC> res = better(partR[tile], s_B[0]);     // the head tile holds the larger p: wins ties
         int64_t r = tr[t]; int b = tb[t];
         opt[(int64_t)b * n1 + r] = res.p;
         nnopt[(int64_t)b * n1 + r] = res.nn;
@@ -408,9 +487,9 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int
 template <typename TC>
 struct LayerWork {
     int64_t n = -1; int nbits = 0;
-    DBuf<int32_t> opt, nnopt, tB, tS0, tr, len, loc, tileF, tileS, carry;
+    DBuf<int32_t> opt, nnopt, cr, tB, tS0, tr, len, loc, tileS;
     DBuf<uint8_t> tb;
-    DBuf<int64_t> offs, scratch, taskR;
+    DBuf<int64_t> offs, scratch, taskR, tilePS, tile_t0;
     DBuf<Best<TC>> partL, partR;
     int64_t max_tasks = 0;
 };
@@ -444,24 +523,47 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     int64_t n = A->n;
     int nbits = 1;
     while (((int64_t)1 << nbits) <= n) nbits++;
+    CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n) {
         Wk.n = n; Wk.nbits = nbits;
-        Wk.opt.alloc((size_t)nbits * (size_t)(n + 1));
-        Wk.nnopt.alloc((size_t)nbits * (size_t)(n + 1));
+        size_t plane = (size_t)nbits * (size_t)(n + 1);
+        Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
         int64_t mx = n;
         for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n); if (R.ntask > mx) mx = R.ntask; }
         Wk.max_tasks = mx > 0 ? mx : 1;
         size_t mt = (size_t)Wk.max_tasks;
         Wk.tB.alloc(mt); Wk.tS0.alloc(mt); Wk.tr.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
     }
+    double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n);
         else make_round(R, false, nbits - rd, nbits, n);
         if (R.ntask <= 0) continue;
+        if (!R.isA) {
+            // right part: every row with ctz == tau streams its 2^tau columns once for all of its bit planes
+            int tau = R.tau;
+            int64_t nrows = ((n >> tau) + 1) >> 1;                     // rows (2u+1)<<tau <= n
+            int64_t cols = nrows << tau;
+            ProfScope ps(PROF_RPASS, s, 4.0 * avg_deg * (double)cols + 8.0 * (double)R.ntask);
+            if (tau <= 3) {
+                hipLaunchKernelGGL(k_rpass_small, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, A->pos.p,
+                                   A->prev.p, Wk.opt.p, Wk.cr.p);
+            } else {
+                int ch_cols = 256;
+                int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
+                if (cpr == 1) ch_cols = 1 << tau;
+                if (cpr > 1)
+                    hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
+                                       Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p);
+                int64_t waves = nrows * cpr;
+                hipLaunchKernelGGL(k_rpass_wave, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols,
+                                   A->pos.p, A->prev.p, Wk.opt.p, Wk.cr.p);
+            }
+        }
         {
-            ProfScope ps(PROF_SETUP, s, 17.0 * (double)R.ntask);
-            hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p,
+            ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
+            hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 0,
                                Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p);
         }
         {
@@ -472,30 +574,31 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         CP_HIP(hipMemcpyAsync(&T, Wk.offs.p + R.ntask, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         CP_HIP(hipStreamSynchronize(s));
         if (T <= 0) continue;
-        int64_t ntile = cdiv(T, TILE);
+        int64_t ntile = cdiv(T, LT);
         Wk.loc.ensure((size_t)T);
-        if (Wk.tileF.n < (size_t)ntile) {
-            Wk.tileF.alloc((size_t)ntile); Wk.tileS.alloc((size_t)ntile); Wk.carry.alloc((size_t)ntile);
+        if (Wk.tileS.n < (size_t)ntile) {
+            Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
             Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
         }
+        CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
+        hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, Wk.tile_t0.p);
         {
-            // algorithmic bytes of the step-count pass: one link entry (4 B) per nonzero of every stepped
-            // column is not known on the host; account per step: colptr pair (16 B) + count out (4 B) here,
-            // the link traffic is added by the bench from the average column degree.
-            ProfScope ps(PROF_EXPAND, s, (double)T);
-            hipLaunchKernelGGL(k_expand, dim3((unsigned)ntile), dim3(TILE_T), 0, s, R, T, Wk.offs.p, Wk.tB.p, Wk.tr.p,
-                               A->pos.p, A->prev.p, A->next.p, Wk.loc.p, Wk.tileF.p, Wk.tileS.p);
+            // algorithmic bytes of one launch: per flattened step the stepped column's link
+            // entries (4 B x N/n), its colptr entry (8 B), the candidate's previous-layer cost (8 B) and the task
+            // descriptor share (offsets/B/anchor/row, amortised 8 B)
+            ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * avg_deg + 24.0));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, R, T, Wk.offs.p, Wk.tB.p,
+                               Wk.tS0.p, Wk.tr.p, Wk.tb.p, A->pos.p, A->next.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.loc.p,
+                               Wk.tileS.p, Wk.partR.p, Wk.taskR.p, Wk.tile_t0.p, (int)g_opt_dbg);
         }
         {
             ProfScope ps(PROF_CARRY, s, 12.0 * (double)ntile);
-            hipLaunchKernelGGL(k_carry, dim3(1), dim3(1024), 0, s, Wk.tileF.p, Wk.tileS.p, Wk.carry.p, ntile);
+            exclusive_scan_i32(Wk.tileS.p, Wk.tilePS.p, ntile, Wk.scratch, s);
         }
-        CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         {
-            ProfScope ps(PROF_EVAL, s, (double)T);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_eval<TC>), dim3((unsigned)ntile), dim3(TILE_T), 0, s, R, T, Wk.offs.p, Wk.tB.p,
-                               Wk.tS0.p, Wk.tr.p, Wk.tb.p, A->pos.p, Wk.loc.p, Wk.carry.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p,
-                               Wk.partL.p, Wk.partR.p, Wk.taskR.p);
+            ProfScope ps(PROF_EVAL, s, 0.0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, R, T, ntile, Wk.offs.p,
+                               Wk.tB.p, Wk.tS0.p, Wk.tr.p, A->pos.p, Wk.loc.p, Wk.tilePS.p, Wk.tile_t0.p, W, M, alpha, Wk.partL.p);
         }
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
