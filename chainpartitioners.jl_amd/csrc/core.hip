@@ -77,7 +77,8 @@ __global__ void __launch_bounds__(1024) k_scan_blocksums(int64_t *__restrict__ b
     if (threadIdx.x == 1023) bsum[nb] = sh[1023];
 }
 
-__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict__ in, int64_t *__restrict__ out,
+template <typename OutT>
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict__ in, OutT *__restrict__ out,
                                                        const int64_t *__restrict__ bsum, int64_t n, int64_t nb)
 {
     __shared__ int64_t sh[SCAN_T];
@@ -96,8 +97,8 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict
     }
     int64_t run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
 #pragma unroll
-    for (int k = 0; k < SCAN_I; k++) if (base + k < n) { out[base + k] = run; run += v[k]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+    for (int k = 0; k < SCAN_I; k++) if (base + k < n) { out[base + k] = (OutT)run; run += v[k]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (OutT)bsum[nb];
 }
 
 void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s)
@@ -107,7 +108,18 @@ void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t
     scratch.ensure((size_t)nb + 1);
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int64_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
+    CP_HIP(hipGetLastError());
+}
+
+void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s)
+{
+    if (n <= 0) { CP_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), s)); return; }
+    int64_t nb = cdiv(n, SCAN_TILE);
+    scratch.ensure((size_t)nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int32_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
     CP_HIP(hipGetLastError());
 }
 

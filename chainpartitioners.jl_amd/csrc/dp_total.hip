@@ -574,6 +574,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         CP_HIP(hipMemcpyAsync(&T, Wk.offs.p + R.ntask, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         CP_HIP(hipStreamSynchronize(s));
         if (T <= 0) continue;
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld T=%lld\n", R.isA, R.tau, (long long)R.ntask, (long long)T);
         int64_t ntile = cdiv(T, LT);
         Wk.loc.ensure((size_t)T);
         if (Wk.tileS.n < (size_t)ntile) {

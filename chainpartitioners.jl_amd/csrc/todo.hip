@@ -4,9 +4,6 @@
 using namespace cpk;
 #define CP_TODO(msg) do { set_error(msg); return CP_EUNSUPPORTED; } while (0)
 extern "C" {
-int32_t cp_count_build(cp_csr_t, int32_t, int32_t, cp_count_t *) { CP_TODO("counting structure build: device path pending"); }
-int32_t cp_count_query(cp_count_t, int64_t, const int64_t *, const int64_t *, int64_t *) { CP_TODO("count query: device path pending"); }
-int32_t cp_count_destroy(cp_count_t) { return CP_OK; }
 int32_t cp_partwise(cp_csr_t, int64_t, const int64_t *, int64_t *, int64_t *, int64_t *, int64_t *, int64_t *) { CP_TODO("partwise: device path pending"); }
 int32_t cp_pack_dynamic(cp_csr_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *, int64_t *) { CP_TODO("pack_stripe(DynamicTotalChunker): device path pending"); }
 int32_t cp_partition_bisect_cost(cp_csr_t, int64_t, const cp_model_t *, double, int32_t, int64_t *) { CP_TODO("BisectCost: device path pending"); }

@@ -1,0 +1,49 @@
+"""GPU parity of the counting structures (dominancecount / netcount / selfnetcount) against brute force
+(test_SparsePrefixMatrices.jl:14, test_SparseColorArrays.jl:1-11) and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from util import (cp, sprand, dense_mask, ref_dominancecount, ref_netcount, ref_selfnetcount, golden_matrices,
+                  suitesparse_shaped)
+
+pytestmark = pytest.mark.gpu
+DIMS = [1, 2, 3, 7, 8, 9]
+
+
+def all_pairs(n1, n2, upper=False):
+    a, b = np.meshgrid(np.arange(1, n1 + 1), np.arange(1, n2 + 1), indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    if upper:
+        k = a <= b
+        a, b = a[k], b[k]
+    return a.astype(np.int64), b.astype(np.int64)
+
+
+@pytest.mark.parametrize("hint", [cp.NoHint(), cp.RandomHint(), cp.SparseHint(), cp.StepHint()])
+def test_counts_match_bruteforce(hip, hint):
+    rng = np.random.default_rng(0xDEADBEEF)
+    mats = [sprand(m, n, 0.5, rng) for m in DIMS for n in DIMS] + [sprand(70, 130, 0.05, rng), sprand(64, 64, 0.2, rng)]
+    for A in mats:
+        D = dense_mask(A)
+        C = cp.dominancecount(A, hint, backend=hip)
+        i, j = all_pairs(A.m + 1, A.n + 1)
+        got = C(i, j)
+        want = np.array([ref_dominancecount(D, a, b) for a, b in zip(i, j)])
+        assert np.array_equal(got, want)
+        net = cp.netcount(A, hint, backend=hip)
+        snet = cp.selfnetcount(A, hint, backend=hip)
+        j, jp = all_pairs(A.n + 1, A.n + 1, upper=True)
+        assert np.array_equal(net(j, jp), np.array([ref_netcount(D, a, b) for a, b in zip(j, jp)]))
+        assert np.array_equal(snet(j, jp), np.array([ref_selfnetcount(D, a, b) for a, b in zip(j, jp)]))
+
+
+def test_counts_match_oracle_on_larger_inputs(hip, orc):
+    rng = np.random.default_rng(3)
+    for A in list(golden_matrices().values()) + [suitesparse_shaped(5000, 7, 4)]:
+        j = rng.integers(1, A.n + 2, 3000); jp = rng.integers(1, A.n + 2, 3000)
+        j, jp = np.minimum(j, jp).astype(np.int64), np.maximum(j, jp).astype(np.int64)
+        i = rng.integers(1, A.m + 2, 3000).astype(np.int64)
+        for kind, f, a, b in (("net", cp.netcount, j, jp), ("selfnet", cp.selfnetcount, j, jp), ("dom", cp.dominancecount, i, jp)):
+            got = f(A, backend=hip)(a, b)
+            want = f(A, backend=orc)(a, b)
+            assert np.array_equal(got, want), kind
