@@ -1,0 +1,167 @@
+// bisect.hip -- partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))
+// (/root/reference/src/BisectCostBottleneckSplitter.jl:6-63, flip :70-127) as ONE kernel launch.
+//
+// The algorithm is a sequential chain by nature: Float64 bisection on the cost c; each probe is K-1 binary
+// searches whose starting point is the previous search's result.  One wave runs it:
+//  * every lane carries the same scalar state (c_lo, c_hi, the three split vectors in HBM), so the control
+//    flow is wave-uniform and bit-identical to the reference's loop (midpoints (c_lo+c_hi)/2, test
+//    c_lo*(1+eps) < c_hi, exact Int64-vs-Float64 comparison);
+//  * inside one binary search the 63 midpoints of the next SIX levels of the decision tree are evaluated at
+//    once, one per lane (for ConnectivityCosts each is an H-level rank query on the wavelet counter), and the
+//    wave then replays the six decisions -- the visited midpoints and the result are exactly those of the
+//    sequential search for ANY cost function, monotone or not.
+#include "csr.hpp"
+#include "model.hpp"
+#include "wavelet.hpp"
+
+namespace cpk {
+
+// v <= c with v::Int64, c::Float64 compared exactly (Julia semantics); Float64 costs compare natively
+__device__ __forceinline__ bool le_f64(int64_t v, double c)
+{
+    if (c != c) return false;
+    if (c >= 9223372036854775808.0) return true;
+    if (c < -9223372036854775808.0) return false;
+    return v <= (int64_t)floor(c);
+}
+__device__ __forceinline__ bool le_f64(double v, double c) { return v <= c; }
+
+template <typename TC>
+struct OracleDev {
+    DevModel<TC> M;
+    const int64_t *pos;
+    int64_t n;
+    int32_t has_net;
+    WaveletDev net;
+};
+
+template <typename TC>
+__device__ __forceinline__ TC oracle_eval_dev(const OracleDev<TC> &O, int64_t j, int64_t jp, int64_t k)
+{
+    int64_t p = j - 1, r = jp - 1;
+    int64_t np = O.pos[r] - O.pos[p];
+    int64_t nn = 0;
+    if (O.has_net) nn = np - wt_count_le(O.net, O.n - p, O.pos[r]);      // SparseColorArrays.jl:121-125
+    return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, nn, (int64_t)0);
+}
+
+template <typename TC>
+__device__ int64_t search6(const OracleDev<TC> &O, int64_t j, int64_t lo, int64_t hi, int64_t k, double c, int flip, int lane)
+{
+    if (lo < j) lo = j;                                   // j'_lo = max(j, j'_lo)  (:17)
+    while (lo <= hi) {
+        int node = lane;                                  // heap index 1..63; lane 0 idles
+        int64_t l = lo, h = hi;
+        bool alive = node >= 1;
+        if (alive) {
+            int depth = 31 - __clz(node);
+            for (int dd = depth - 1; dd >= 0; dd--) {
+                if (l > h) break;
+                int64_t mid = (int64_t)(((uint64_t)(l + h)) >> 1);
+                if ((node >> dd) & 1) l = mid + 1; else h = mid - 1;
+            }
+        }
+        bool has = alive && l <= h;
+        int64_t mid = (int64_t)(((uint64_t)(l + h)) >> 1);
+        bool le = false;
+        if (has) le = le_f64(oracle_eval_dev(O, j, mid, k), c);
+        unsigned long long lem = __ballot(le), hasm = __ballot(has);
+        int nd = 1;
+        for (int step = 0; step < 6; step++) {
+            if (!((hasm >> nd) & 1)) break;
+            int64_t m2 = (int64_t)(((uint64_t)(lo + hi)) >> 1);
+            bool isle = (lem >> nd) & 1;
+            bool right;
+            if (!flip) { if (isle) { lo = m2 + 1; right = true; } else { hi = m2 - 1; right = false; } }
+            else       { if (isle) { hi = m2 - 1; right = false; } else { lo = m2 + 1; right = true; } }
+            nd = 2 * nd + (right ? 1 : 0);
+        }
+    }
+    return flip ? lo : hi;
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, double c_lo, double c_hi, double eps, int flip,
+                                               int64_t *__restrict__ spl_lo, int64_t *__restrict__ spl_hi, int64_t *__restrict__ spl,
+                                               int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
+{
+    int lane = threadIdx.x;
+    int64_t n = O.n;
+    // every lane performs every (wave-uniform) store, so each lane later reads its own writes
+    for (int64_t k = 1; k <= K + 1; k++) { spl_lo[k - 1] = 1; spl_hi[k - 1] = n + 1; spl[k - 1] = 0; }
+    spl_lo[K] = n + 1;
+    spl_hi[0] = 1;
+    spl[0] = 1;
+    spl[K] = n + 1;
+    int64_t probes = 0;
+    while (c_lo * (1 + eps) < c_hi) {                     // :41
+        double c = (c_lo + c_hi) / 2;
+        probes++;
+        spl[0] = 1;
+        bool chk = true;
+        for (int64_t k = 1; k <= K - 1; k++) {
+            int64_t j = spl[k - 1];
+            int64_t rr = search6(O, j, spl_lo[k], spl_hi[k], k, c, flip, lane);
+            spl[k] = rr;
+            if (!flip) {
+                if (rr < j) { chk = false; for (int64_t t = k + 1; t <= K; t++) spl[t - 1] = j; break; }
+            } else {
+                if (rr > n + 1) { chk = false; for (int64_t t = k + 1; t <= K; t++) spl[t - 1] = n + 1; break; }
+            }
+        }
+        bool feas = false;
+        if (chk) feas = le_f64(oracle_eval_dev(O, spl[K - 1], spl[K], K), c);
+        if (feas) {
+            c_hi = c;
+            int64_t *dst = flip ? spl_lo : spl_hi;
+            for (int64_t k = 0; k <= K; k++) dst[k] = spl[k];
+        } else {
+            c_lo = c;
+            int64_t *dst = flip ? spl_hi : spl_lo;
+            for (int64_t k = 0; k <= K; k++) dst[k] = spl[k];
+        }
+    }
+    const int64_t *src = flip ? spl_lo : spl_hi;
+    for (int64_t k = lane; k <= K; k += 64) out[k] = src[k];
+    if (lane == 0) *nprobes = probes;
+}
+
+template <typename TC>
+int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, double c_hi, double eps, int flip, int64_t *spl_out)
+{
+    hipStream_t s = A->stream;
+    HostModel<TC> HM;
+    build_dev_model<TC>(mdl, HM, s);
+    OracleDev<TC> O;
+    O.M = HM.d; O.pos = A->pos.p; O.n = A->n; O.has_net = 0;
+    WaveletHost net;
+    if (mdl->kind == CP_MODEL_CONNECTIVITY) { ensure_net_counter(A, net); O.has_net = 1; O.net = net.d; }
+    DBuf<int64_t> buf((size_t)(4 * (K + 1) + 1));
+    int64_t *d_lo = buf.p, *d_hi = buf.p + (K + 1), *d_spl = buf.p + 2 * (K + 1), *d_out = buf.p + 3 * (K + 1), *d_np = buf.p + 4 * (K + 1);
+    {
+        ProfScope ps(PROF_BISECT, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect<TC>), dim3(1), dim3(64), 0, s, O, K, c_lo, c_hi, eps, flip, d_lo, d_hi, d_spl, d_out, d_np);
+    }
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipMemcpyAsync(spl_out, d_out, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    return CP_OK;
+}
+
+}  // namespace cpk
+
+using namespace cpk;
+
+extern "C" int32_t cp_partition_bisect_cost(cp_csr_t A, int64_t K, const cp_model_t *model, double eps, int32_t flip, int64_t *spl_out)
+{
+    try {
+        CP_REQUIRE(A && model && spl_out && K >= 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        int64_t li, hi; double lf, hf;
+        int32_t rc = cp_bound_stripe(A, K, model, &li, &hi, &lf, &hf);        // (c_lo, c_hi) = bound_stripe(...) ./ 1  (:39)
+        if (rc != CP_OK) return rc;
+        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, lf, hf, eps, flip, spl_out);
+        return run_bisect<double>(A, K, model, lf, hf, eps, flip, spl_out);
+    } catch (const HipFail &e) { return e.code; }
+}

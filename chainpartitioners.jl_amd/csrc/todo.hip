@@ -6,7 +6,6 @@ using namespace cpk;
 extern "C" {
 int32_t cp_partwise(cp_csr_t, int64_t, const int64_t *, int64_t *, int64_t *, int64_t *, int64_t *, int64_t *) { CP_TODO("partwise: device path pending"); }
 int32_t cp_pack_dynamic(cp_csr_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *, int64_t *) { CP_TODO("pack_stripe(DynamicTotalChunker): device path pending"); }
-int32_t cp_partition_bisect_cost(cp_csr_t, int64_t, const cp_model_t *, double, int32_t, int64_t *) { CP_TODO("BisectCost: device path pending"); }
 int32_t cp_pack_convex(cp_csr_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *, int64_t *) { CP_TODO("ConvexTotalChunker: device path pending"); }
 int32_t cp_partition_convex(cp_csr_t, int64_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *) { CP_TODO("ConvexTotalSplitter: device path pending"); }
 }

@@ -1,0 +1,40 @@
+"""GPU parity: [Flip]BisectCostBottleneckSplitter (one-launch device kernel) vs the CPU oracle; bit-exact
+split vectors including the Float64 bisection path."""
+import numpy as np
+import pytest
+
+from util import cp, sprand, golden_matrices, suitesparse_shaped
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bisect_cost_matches_oracle(hip, orc):
+    rng = np.random.default_rng(12)
+    mats = [sprand(m, n, 0.3, rng) for m in (1, 3, 8) for n in (1, 2, 3, 8, 40)] + list(golden_matrices().values())
+    mats += [suitesparse_shaped(20000, 8, 6)]
+    for A in mats:
+        for K in (1, 2, 3, 8, 32):
+            for f in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineConnectivityModel(0, 3, 1, 3),
+                      cp.AffineConnectivityModel(0.5, 0.25, 1.0, 3.0), cp.AffineWorkModel(2.5, 0.5, 1.25)):
+                for eps in (0.1, 0.01, 0.001):
+                    got = cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(f, eps), backend=hip)
+                    want = cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(f, eps), backend=orc)
+                    assert got == want, (A, K, f.kind, f.dtype, eps)
+            # decreasing cost for the Flip variant: alpha large, negative betas (bound_stripe: c_hi = alpha)
+            f = cp.AffineWorkModel(1 + A.nnz + 3 * A.n, -3, -1)
+            for eps in (0.1, 0.001):
+                got = cp.partition_stripe(A, K, cp.FlipBisectCostBottleneckSplitter(f, eps), backend=hip)
+                want = cp.partition_stripe(A, K, cp.FlipBisectCostBottleneckSplitter(f, eps), backend=orc)
+                assert got == want, (A, K, "flip", eps)
+
+
+def test_bisect_within_eps_of_optimum(hip):
+    """test_Partitioners.jl:112: bottleneck <= (1+eps) * optimal bottleneck (optimal from the device DP)."""
+    A = suitesparse_shaped(3000, 6, 2)
+    for f in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+        for K in (2, 7):
+            opt = cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(f), backend=hip)
+            c = cp.bottleneck_value(A, opt, f, backend=hip)
+            for eps in (0.1, 0.01):
+                got = cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(f, eps), backend=hip)
+                assert cp.bottleneck_value(A, got, f, backend=hip) <= c * (1 + eps)
