@@ -360,13 +360,17 @@ int32_t cp_pack_equi(int64_t n, int64_t w, int64_t *spl_out, int64_t *K_out)
 int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t order, const cp_model_t *model,
                              const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64, double wmax_f64, int64_t *spl_out)
 {
-    (void)wmax_i64; (void)wmax_f64; (void)Pi;
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && spl_out && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
         CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
         CP_HIP(hipSetDevice(A->device));
         bool constrained = weight && weight->kind != CP_MODEL_FEASIBLE;
-        CP_REQUIRE(!constrained, CP_EUNSUPPORTED, "ConstrainedCost DP variants are not on the device path yet");
+        if (constrained) {
+            CP_REQUIRE(weight->kind == CP_MODEL_VERTEX_COUNT || (weight->kind == CP_MODEL_WORK && !weight->alpha_k), CP_EINVAL,
+                       "weight must be VertexCount or an AffineWorkModel");
+            if (model->dtype == CP_I64) return run_dyn_constrained<int64_t>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+            return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+        }
         CP_REQUIRE(model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT ||
                        model->kind == CP_MODEL_COLBLOCK,
                    CP_EUNSUPPORTED, "model kind has no device DP path yet");
@@ -391,11 +395,14 @@ int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model
 int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint, int64_t nq,
                        const int64_t *j, const int64_t *jp, const int64_t *k, int64_t *out_i64, double *out_f64)
 {
-    (void)hint; (void)Pi;
+    (void)hint;
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && model_known(model) && (nq == 0 || (j && jp)), CP_EINVAL, "bad argument");
-        CP_REQUIRE(model->kind != CP_MODEL_BLOCK, CP_EUNSUPPORTED, "BlockComponentCostModel oracle is not on the device path yet");
         CP_HIP(hipSetDevice(A->device));
+        if (model->kind == CP_MODEL_BLOCK) {          // stateful step oracle: evaluated in query order by one wave (seq.hip)
+            if (model->dtype == CP_I64) return run_seq_eval<int64_t>(A, model, Pi, nq, j, jp, k, out_i64);
+            return run_seq_eval<double>(A, model, Pi, nq, j, jp, k, out_f64);
+        }
         if (model->dtype == CP_I64) return run_oracle_eval<int64_t>(A, model, nq, j, jp, k, out_i64);
         return run_oracle_eval<double>(A, model, nq, j, jp, k, out_f64);
     });

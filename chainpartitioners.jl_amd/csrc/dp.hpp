@@ -17,6 +17,14 @@ template <typename TC>
 void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combine, const TC *W, TC *cst_out,
                     int32_t *ptr_out, int64_t r_lo, int64_t r_hi);
 
+// seq.hip
+template <typename TC>
+int32_t run_dyn_constrained(cp_csr_s *A, int64_t K, int32_t g, int32_t order, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                            const cp_model_t *w, int64_t wi, double wf, int64_t *spl_out);
+template <typename TC>
+int32_t run_seq_eval(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int64_t *j, const int64_t *jp,
+                     const int64_t *k, TC *out);
+
 extern int64_t g_opt_force_brute;      // cp_set_option("force_brute", 1)
 extern int64_t g_opt_brute_max_n;
 extern int64_t g_opt_dbg;            // timing experiments only (cp_set_option("dbg", mask)); results are wrong when non-zero      // largest n the O(n^2) path accepts

@@ -1,0 +1,748 @@
+// seq.hip -- the inherently sequential partitioners of the hot path, run on the device by ONE wave whose
+// 64 lanes execute the same scalar program (every lane performs every store, so a lane only ever reads what it
+// wrote itself) and fan out only where the reference has an independent inner loop:
+//
+//   pack_stripe(A, DynamicTotalChunker(f | ConstrainedCost(f,w,w_max)))          DynamicChunker.jl:20-75
+//   partition_stripe(A, K, Dynamic*{Splitter,Chunker}(ConstrainedCost(...)))      DynamicSplitter.jl:206-314
+//   pack_stripe / partition_stripe with ConvexTotal{Chunker,Splitter}             ConvexTotalChunker.jl:9-265
+//
+// Oracle values come from the device counters (wavelet rank queries for nets / self-nets, colptr for pins),
+// or from the stateful block oracle (BlockCosts.jl:66-142) restated on device arrays.  Tie rules, the
+// Extended{T} infinity arithmetic and the WindowConstrainedMatrix read/write semantics follow the reference
+// statement for statement.  These kernels are latency-bound by design (one dependent chain); the throughput
+// paths are dp_total.hip / bisect.hip.
+#include "csr.hpp"
+#include "model.hpp"
+#include "wavelet.hpp"
+#include <memory>
+
+namespace cpk {
+
+// ------------------------------------------------------------------ device oracle ocl(j, j', k)
+template <typename TC>
+struct SeqOracle {
+    DevModel<TC> M;
+    const int64_t *pos;
+    const int32_t *row;
+    int64_t n, m;
+    int32_t has_net, has_self;
+    WaveletDev net, self;
+    const int64_t *lpos;
+    // BlockComponentCostStepOracle state (BlockCosts.jl:46-64), all on device
+    const int32_t *P_asg;      // m   : part of each row (1-based part ids)
+    const int64_t *P_spl;      // Kr+1 (1-based values)
+    int64_t Kr;
+    int64_t *hst;              // Kr
+    TC *Delta;                 // R x (n+1), column-major
+    TC *d;                     // R
+    int64_t *cursor;           // [0] = ocl.j, [1] = ocl.j'
+    // block-row components
+    int32_t br_const[CP_MAX_R]; TC br_c[CP_MAX_R]; const TC *br_tab[CP_MAX_R]; int64_t br_len[CP_MAX_R];
+};
+
+template <typename TC>
+__device__ TC block_call(const SeqOracle<TC> &O, int64_t j, int64_t jp)
+{
+    const DevModel<TC> &f = O.M;
+    int R = f.R;
+    int64_t oj = O.cursor[0], ojp = O.cursor[1];
+    TC *d = O.d, *Dl = O.Delta;
+#define DL(r, c) Dl[((c) - 1) * R + ((r) - 1)]
+    if (jp < ojp) {                                          // :82-87
+        oj = 1; ojp = 1;
+        for (int r = 0; r < R; r++) d[r] = (TC)0;
+        for (int64_t k = 1; k <= O.Kr; k++) O.hst[k - 1] = 1;
+    }
+    while (ojp < jp) {                                       // :88-118
+        int64_t q = O.pos[ojp - 1], qp = O.pos[ojp];          // 0-based nonzero range of column ojp
+        for (int r = 1; r <= R; r++) DL(r, ojp + 1) = (TC)0;
+        for (int64_t _q = q; _q < qp; _q++) {
+            int64_t i = O.row[_q];                            // 0-based row
+            int64_t k = O.P_asg[i];
+            int64_t j0 = O.hst[k - 1] - 1;
+            int64_t u = O.P_spl[k] - O.P_spl[k - 1];
+            if (j0 < ojp) {
+                for (int r = 1; r <= R; r++) DL(r, j0 + 1) = cadd(DL(r, j0 + 1), (TC)0 - dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
+                for (int r = 1; r <= R; r++) DL(r, ojp + 1) = cadd(DL(r, ojp + 1), dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
+            }
+            if (j0 < oj)
+                for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
+            O.hst[k - 1] = ojp + 1;
+        }
+        ojp += 1;
+    }
+    while (j < oj) { oj -= 1; for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], DL(r, oj + 1)); }
+    while (j > oj) { for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], (TC)0 - DL(r, oj + 1)); oj += 1; }
+#undef DL
+    int64_t w = jp - j;
+    TC c = dm_comp(f.ac_const, f.ac_c, f.ac_tab, f.ac_len, w);
+    for (int r = 1; r <= R; r++) c = cadd(c, cmulv(d[r - 1], dm_comp(f.bc_const[r - 1], f.bc_c[r - 1], f.bc_tab[r - 1], f.bc_len[r - 1], w)));
+    O.cursor[0] = oj; O.cursor[1] = ojp;
+    return c;
+}
+
+template <typename TC>
+__device__ TC ocl(const SeqOracle<TC> &O, int64_t j, int64_t jp, int64_t k)
+{
+    if (O.M.kind == CP_MODEL_BLOCK) return block_call(O, j, jp);
+    int64_t p = j - 1, r = jp - 1;
+    int64_t np = O.pos[r] - O.pos[p];
+    int64_t nn = 0, nl = 0;
+    if (O.has_net) nn = np - wt_count_le(O.net, O.n - p, O.pos[r]);
+    if (O.has_self) nl = wt_count_le(O.self, O.n - p, O.lpos[r]);
+    return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, nn, nl);
+}
+
+// ------------------------------------------------------------------ weights of ConstrainedCost
+struct SeqWeight {
+    int32_t kind;          // FEASIBLE / VERTEX_COUNT / WORK
+    int32_t dtype;
+    int64_t pi[3]; double pf[3];
+    int64_t wmax_i; double wmax_f;
+    const int64_t *pos;
+};
+__device__ __forceinline__ bool wgt_gt(const SeqWeight &W, int64_t j, int64_t jp)
+{
+    if (W.kind == CP_MODEL_FEASIBLE) return false;
+    if (W.kind == CP_MODEL_VERTEX_COUNT) return (jp - j) > W.wmax_i;
+    int64_t nv = jp - j, np = W.pos[jp - 1] - W.pos[j - 1];
+    if (W.dtype == CP_I64) return (W.pi[0] + nv * W.pi[1] + np * W.pi[2]) > W.wmax_i;
+    return (W.pf[0] + (double)nv * W.pf[1] + (double)np * W.pf[2]) > W.wmax_f;
+}
+__device__ __forceinline__ bool wgt_le(const SeqWeight &W, int64_t j, int64_t jp) { return !wgt_gt(W, j, jp); }
+
+#define A1(a, k) ((a)[(k) - 1])
+
+// ------------------------------------------------------------------ pack_stripe, DynamicTotalChunker (DynamicChunker.jl:20-56)
+// candidates j = j0 .. j'-1 of one row are evaluated by the lanes in parallel (stateless models); strict <
+// while scanning j upwards == the smallest j among the minima.
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_dynamic(SeqOracle<TC> O, SeqWeight W, TC *__restrict__ cst, int64_t *__restrict__ spl,
+                                                     int32_t *__restrict__ status)
+{
+    int lane = threadIdx.x;
+    int64_t n = O.n;
+    bool serial = O.M.kind == CP_MODEL_BLOCK;             // the block oracle is stateful: literal serial sweep
+    A1(cst, 1) = (TC)0;
+    int64_t j0 = 1;
+    for (int64_t jp = 2; jp <= n + 1; jp++) {
+        while (wgt_gt(W, j0, jp)) j0 += 1;
+        if (!(j0 < jp)) { *status = CP_EINVAL; return; }   // @assert j0 < j'
+        TC best_c; int64_t best_j;
+        if (serial) {
+            best_c = cadd(A1(cst, j0), ocl(O, j0, jp, 0)); best_j = j0;
+            for (int64_t j = j0 + 1; j <= jp - 1; j++) {
+                TC c = cadd(A1(cst, j), ocl(O, j, jp, 0));
+                if (c < best_c) { best_c = c; best_j = j; }
+            }
+        } else {
+            bool have = false; best_c = (TC)0; best_j = 0;
+            for (int64_t j = j0 + lane; j <= jp - 1; j += 64) {
+                TC c = cadd(A1(cst, j), ocl(O, j, jp, 0));
+                if (!have || c < best_c) { best_c = c; best_j = j; have = true; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                int src = (lane + o) & 63;
+                int oh = __shfl((int)have, src);
+                int64_t oj;
+                TC oc;
+                {
+                    int lo = __shfl((int)(best_j & 0xffffffffll), src), hi = __shfl((int)(best_j >> 32), src);
+                    oj = ((int64_t)hi << 32) | (uint32_t)lo;
+                    union { TC t; int2 i; } u; u.t = best_c;
+                    int2 r2; r2.x = __shfl(u.i.x, src); r2.y = __shfl(u.i.y, src);
+                    union { TC t; int2 i; } v; v.i = r2; oc = v.t;
+                }
+                if (lane + o < 64 && oh && (!have || oc < best_c || (oc == best_c && oj < best_j))) { best_c = oc; best_j = oj; have = true; }
+            }
+            // broadcast lane 0's result
+            {
+                int lo = __shfl((int)(best_j & 0xffffffffll), 0), hi = __shfl((int)(best_j >> 32), 0);
+                best_j = ((int64_t)hi << 32) | (uint32_t)lo;
+                union { TC t; int2 i; } u; u.t = best_c;
+                int2 r2; r2.x = __shfl(u.i.x, 0); r2.y = __shfl(u.i.y, 0);
+                union { TC t; int2 i; } v; v.i = r2; best_c = v.t;
+            }
+        }
+        A1(cst, jp) = best_c;
+        A1(spl, jp) = best_j;
+    }
+}
+
+// ------------------------------------------------------------------ Extended{T} (Costs.jl:79-103)
+template <typename TC> struct Ext { int32_t inf; TC x; };
+template <typename TC> __device__ __forceinline__ Ext<TC> ext_of(TC x) { Ext<TC> e; e.inf = 0; e.x = x; return e; }
+template <typename TC> __device__ __forceinline__ Ext<TC> ext_inf() { Ext<TC> e; e.inf = 1; e.x = (TC)0; return e; }
+template <typename TC> __device__ __forceinline__ Ext<TC> ext_add(Ext<TC> a, Ext<TC> b) { Ext<TC> e; e.inf = a.inf | b.inf; e.x = cadd(a.x, b.x); return e; }
+template <typename TC> __device__ __forceinline__ bool ext_lt(Ext<TC> a, Ext<TC> b) { return (!a.inf && b.inf) || ((!a.inf && !b.inf) && (a.x < b.x)); }
+template <typename TC> __device__ __forceinline__ bool ext_eq(Ext<TC> a, Ext<TC> b) { return (a.inf && b.inf) || ((!a.inf && !b.inf) && (a.x == b.x)); }
+template <typename TC> __device__ __forceinline__ bool ext_le(Ext<TC> a, Ext<TC> b) { return ext_lt(a, b) || ext_eq(a, b); }
+
+// the f' closure handed to chunk_convex! (ConvexTotalChunker.jl:19,46,199,246)
+template <typename TC>
+struct Cvx {
+    int mode;                  // 0: base[j] + extend(f(j,j',k))   3: sigma re-indexing of `inner`
+    int64_t k;
+    const Ext<TC> *base; int64_t blo, bhi;       // base[j] valid for j in [blo,bhi] (1-based index into base)
+    const Cvx<TC> *inner; const int64_t *sig_j, *sig_jp; int64_t I;
+};
+
+template <typename TC>
+__device__ Ext<TC> cvx_eval(const SeqOracle<TC> &O, const Cvx<TC> &F, int64_t j, int64_t jp)
+{
+    if (F.mode == 3) { j = A1(F.sig_j, F.I - j); jp = A1(F.sig_jp, F.I - jp); const Cvx<TC> &G = *F.inner;
+        Ext<TC> b = (G.blo <= j && j <= G.bhi) ? G.base[j] : ext_inf<TC>();
+        return ext_add(b, ext_of(ocl(O, j, jp, G.k))); }
+    Ext<TC> b = (F.blo <= j && j <= F.bhi) ? F.base[j] : ext_inf<TC>();
+    return ext_add(b, ext_of(ocl(O, j, jp, F.k)));
+}
+
+// destination view with WindowConstrainedMatrix semantics (reads outside give infinity, writes are dropped)
+template <typename TC>
+struct CView { Ext<TC> *cst; int64_t *ptr; int64_t lo, hi; };
+template <typename TC> __device__ __forceinline__ Ext<TC> cv_get(const CView<TC> &V, int64_t jp) { return (V.lo <= jp && jp <= V.hi) ? V.cst[jp] : ext_inf<TC>(); }
+template <typename TC> __device__ __forceinline__ void cv_set(const CView<TC> &V, int64_t jp, Ext<TC> c, int64_t p) { if (V.lo <= jp && jp <= V.hi) { V.cst[jp] = c; V.ptr[jp] = p; } }
+
+// chunk_convex!(cst, ptr, f, j0, j'1, ftr)  ConvexTotalChunker.jl:57-112 ; ftr = stack of (j, h) pairs
+template <typename TC>
+__device__ void chunk_convex(const SeqOracle<TC> &O, const CView<TC> &V, const Cvx<TC> &F, int64_t j0, int64_t jp1, int64_t *ftr)
+{
+    int64_t top = 0;
+#define PUSH(a, b) do { ftr[2 * top] = (a); ftr[2 * top + 1] = (b); top++; } while (0)
+    PUSH(j0, jp1 + 1);
+    for (int64_t jp = j0 + 1; jp <= jp1; jp++) {
+        int64_t j = ftr[2 * (top - 1)], h = ftr[2 * (top - 1) + 1];
+        Ext<TC> c = cvx_eval(O, F, j, jp);
+        Ext<TC> c2 = cvx_eval(O, F, jp - 1, jp);
+        if (ext_le(c, c2)) {
+            if (ext_le(c, cv_get(V, jp))) cv_set(V, jp, c, j);
+            if (h == jp + 1) top--;
+        } else {
+            if (ext_le(c2, cv_get(V, jp))) cv_set(V, jp, c2, jp - 1);
+            while (top > 0) {
+                j = ftr[2 * (top - 1)]; h = ftr[2 * (top - 1) + 1];
+                if (ext_lt(cvx_eval(O, F, jp - 1, h - 1), cvx_eval(O, F, j, h - 1))) top--; else break;
+            }
+            if (top == 0) {
+                PUSH(jp - 1, jp1 + 1);
+            } else {
+                j = ftr[2 * (top - 1)]; h = ftr[2 * (top - 1) + 1];
+                int64_t h_lo = jp + 1, h_hi = h - 1;
+                while (h_lo <= h_hi) {
+                    h = (int64_t)(((uint64_t)(h_lo + h_hi)) >> 1);
+                    if (ext_lt(cvx_eval(O, F, jp - 1, h - 1), cvx_eval(O, F, j, h - 1))) h_lo = h + 1; else h_hi = h - 1;
+                }
+                h = h_hi;
+                if (jp + 1 != h) PUSH(jp - 1, h);
+            }
+        }
+    }
+#undef PUSH
+}
+
+// chunk_convex_constrained!  ConvexTotalChunker.jl:211-265
+template <typename TC>
+__device__ int32_t chunk_convex_constrained(const SeqOracle<TC> &O, const CView<TC> &V, const Cvx<TC> &F, const SeqWeight &W,
+                                            int64_t J0, int64_t Jp1, int64_t *ftr, int64_t *sig_j, int64_t *sig_jp,
+                                            int64_t *sig_ptr, Ext<TC> *sig_cst)
+{
+    int64_t jp1 = J0 + 1;
+    while (jp1 < Jp1 && wgt_le(W, J0, jp1 + 1)) jp1 += 1;
+    int64_t j0 = J0;
+    for (;;) {
+        chunk_convex(O, V, F, j0, jp1, ftr);
+        if (jp1 == Jp1) break;
+        int64_t jp = jp1, I = 1;
+        for (int64_t j = j0 + 1; j <= jp1; j++) {
+            if (jp > jp1) { A1(sig_jp, I) = jp; I += 1; A1(sig_j, I) = j; }
+            while (jp < Jp1 && wgt_le(W, j, jp + 1)) { jp += 1; A1(sig_jp, I) = jp; I += 1; A1(sig_j, I) = j; }
+        }
+        I += 1;
+        if (I == 2) return CP_EINVAL;          // a single column exceeds w_max (the reference indexes sigma_j'[0])
+        for (int64_t i = 2; i <= I - 1; i++) sig_cst[i] = ext_inf<TC>();
+        Cvx<TC> G; G.mode = 3; G.k = 0; G.base = nullptr; G.blo = 0; G.bhi = -1; G.inner = &F; G.sig_j = sig_j; G.sig_jp = sig_jp; G.I = I;
+        CView<TC> SV; SV.cst = sig_cst; SV.ptr = sig_ptr; SV.lo = 1; SV.hi = I - 1;
+        chunk_convex(O, SV, G, (int64_t)1, I - 1, ftr);
+        for (int64_t ip = 2; ip <= I - 1; ip++) cv_set(V, A1(sig_jp, I - ip), sig_cst[ip], A1(sig_j, I - sig_ptr[ip]));
+        j0 = jp1;
+        jp1 = A1(sig_jp, I - 2);
+    }
+    return CP_OK;
+}
+
+// pack_stripe(A, ConvexTotalChunker(..))  :9-24, :141-168 ; all arrays are 1-based at index j' (slot 0 unused)
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_convex(SeqOracle<TC> O, SeqWeight W, int constrained, Ext<TC> *cst, int64_t *ptr,
+                                                    int64_t *ftr, int64_t *sig_j, int64_t *sig_jp, int64_t *sig_ptr, Ext<TC> *sig_cst,
+                                                    int32_t *status)
+{
+    int64_t n = O.n;
+    for (int64_t t = 0; t <= n + 1; t++) { cst[t] = ext_inf<TC>(); ptr[t] = 0; }
+    cst[1] = ext_of((TC)0);
+    Cvx<TC> F; F.mode = 0; F.k = 0; F.base = cst; F.blo = 1; F.bhi = n + 1; F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0;
+    CView<TC> V; V.cst = cst; V.ptr = ptr; V.lo = 1; V.hi = n + 1;
+    int32_t rc = CP_OK;
+    if (!constrained) chunk_convex(O, V, F, (int64_t)1, n + 1, ftr);
+    else if (n >= 1) rc = chunk_convex_constrained(O, V, F, W, (int64_t)1, n + 1, ftr, sig_j, sig_jp, sig_ptr, sig_cst);
+    if (threadIdx.x == 0) *status = rc;
+}
+
+// column_constraints  DynamicSplitter.jl:144-172
+__device__ void column_constraints(int64_t n, int64_t K, const SeqWeight &W, int64_t *jlo, int64_t *jhi)
+{
+    int64_t jp = n + 1;
+    for (int64_t k = K; k >= 1; k--) {
+        A1(jlo, k) = jp;
+        int64_t j = jp;
+        while (j - 1 >= 1 && wgt_le(W, j - 1, jp)) j -= 1;
+        jp = j;
+    }
+    int64_t j = 1;
+    for (int64_t k = 1; k <= K; k++) {
+        jp = j;
+        while (jp + 1 <= n + 1 && wgt_le(W, j, jp + 1)) jp += 1;
+        A1(jhi, k) = jp;
+        j = jp;
+    }
+}
+
+// part_constraints  DynamicSplitter.jl:174-204
+__device__ void part_constraints(int64_t n, int64_t K, const SeqWeight &W, int64_t *klo, int64_t *khi)
+{
+    for (int64_t t = 1; t <= n + 1; t++) { A1(klo, t) = 0; A1(khi, t) = 0; }
+    int64_t jp = n + 1;
+    A1(khi, n + 1) = K;
+    for (int64_t k = K; k >= 1; k--) {
+        int64_t j = jp;
+        while (j - 1 >= 1 && wgt_le(W, j - 1, jp)) { j -= 1; A1(khi, j) = k - 1; }
+        jp = j;
+    }
+    int64_t j = 1;
+    A1(klo, 1) = 1;
+    for (int64_t k = 1; k <= K; k++) {
+        jp = j;
+        while (jp + 1 <= n + 1 && wgt_le(W, j, jp + 1)) { jp += 1; A1(klo, jp) = k; }
+        j = jp;
+    }
+}
+
+// partition_stripe(A, K, ConvexTotalSplitter(..))  :26-55, :170-209.  cst/ptr: K layers of (n+2) slots.
+template <typename TC>
+__global__ void __launch_bounds__(64) k_partition_convex(SeqOracle<TC> O, SeqWeight W, int constrained, int64_t K, Ext<TC> *cst, int64_t *ptr,
+                                                         int64_t *jlo, int64_t *jhi, int64_t *ftr, int64_t *sig_j, int64_t *sig_jp,
+                                                         int64_t *sig_ptr, Ext<TC> *sig_cst, int64_t *spl, int32_t *status)
+{
+    int64_t n = O.n, ld = n + 2;
+    if (constrained) {
+        column_constraints(n, K, W, jlo, jhi);
+        if (A1(jhi, K) < n + 1) {
+            for (int64_t k = 1; k <= K + 1; k++) A1(spl, k) = 1;
+            A1(spl, K + 1) = n + 1;
+            if (threadIdx.x == 0) *status = CP_INFEASIBLE;
+            return;
+        }
+    } else {
+        for (int64_t k = 1; k <= K; k++) { A1(jlo, k) = 1; A1(jhi, k) = n + 1; }
+    }
+    for (int64_t t = 0; t < ld * K; t++) { cst[t] = ext_inf<TC>(); ptr[t] = 0; }
+    for (int64_t jp = A1(jlo, 1); jp <= A1(jhi, 1); jp++) { cst[jp] = ext_of(ocl(O, 1, jp, 1)); ptr[jp] = 1; }
+    int32_t rc = CP_OK;
+    for (int64_t k = 2; k <= K && rc == CP_OK; k++) {
+        Cvx<TC> F; F.mode = 0; F.k = k; F.base = cst + (k - 2) * ld; F.blo = A1(jlo, k - 1); F.bhi = A1(jhi, k - 1);
+        F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0;
+        CView<TC> V; V.cst = cst + (k - 1) * ld; V.ptr = ptr + (k - 1) * ld; V.lo = A1(jlo, k); V.hi = A1(jhi, k);
+        for (int64_t jp = A1(jlo, k); jp <= A1(jhi, k); jp++) cv_set(V, jp, cvx_eval(O, F, jp, jp), jp);
+        if (!constrained) chunk_convex(O, V, F, (int64_t)1, n + 1, ftr);
+        else rc = chunk_convex_constrained(O, V, F, W, A1(jlo, k - 1), A1(jhi, k), ftr, sig_j, sig_jp, sig_ptr, sig_cst);
+    }
+    if (rc == CP_OK) {
+        A1(spl, K + 1) = n + 1;
+        for (int64_t k = K; k >= 1; k--) {
+            int64_t jp = A1(spl, k + 1);
+            A1(spl, k) = (A1(jlo, k) <= jp && jp <= A1(jhi, k)) ? ptr[(k - 1) * ld + jp] : 0;
+        }
+    }
+    if (threadIdx.x == 0) *status = rc;
+}
+
+// ------------------------------------------------------------------ constrained K-part DPs (DynamicSplitter.jl:206-314)
+// window-constrained tables stored ragged like WindowConstrainedMatrix: val[pos[c] + i - lo[c]]
+template <typename TC>
+__global__ void __launch_bounds__(64) k_dyn_constrained(SeqOracle<TC> O, SeqWeight W, int64_t K, int32_t g, int32_t order,
+                                                        int64_t *lo, int64_t *hi, int64_t *wpos, TC *cv, int64_t *pv, int64_t cap,
+                                                        int64_t *spl, int32_t *status)
+{
+    int64_t n = O.n;
+    const TC TMAX = CostTraits<TC>::typemax();
+    if (order == CP_ORDER_SPLITTER) {                       // :206-258 ; columns of the window matrix = parts k
+        column_constraints(n, K, W, lo, hi);
+        if (A1(hi, K) < n + 1) {
+            for (int64_t k = 1; k <= K + 1; k++) A1(spl, k) = 1;
+            A1(spl, K + 1) = n + 1;
+            if (threadIdx.x == 0) *status = CP_INFEASIBLE;
+            return;
+        }
+        A1(wpos, 1) = 1;
+        for (int64_t k = 1; k <= K; k++) A1(wpos, k + 1) = A1(wpos, k) + A1(hi, k) - A1(lo, k) + 1;
+        if (A1(wpos, K + 1) - 1 > cap) { if (threadIdx.x == 0) *status = CP_EUNSUPPORTED; return; }
+#define IN(i, c) (A1(lo, c) <= (i) && (i) <= A1(hi, c))
+#define AT(i, c) (A1(wpos, c) + (i) - A1(lo, c))
+#define CGET(i, c) (IN(i, c) ? A1(cv, AT(i, c)) : TMAX)
+#define CSET(i, c, v) do { if (IN(i, c)) A1(cv, AT(i, c)) = (v); } while (0)
+#define PGET(i, c) (IN(i, c) ? A1(pv, AT(i, c)) : (int64_t)0)
+#define PSET(i, c, v) do { if (IN(i, c)) A1(pv, AT(i, c)) = (v); } while (0)
+        for (int64_t jp = A1(lo, 1); jp <= A1(hi, 1); jp++) { CSET(jp, 1, ocl(O, 1, jp, 1)); PSET(jp, 1, 1); }
+        for (int64_t k = 2; k <= K; k++) {
+            int64_t j0 = A1(lo, k - 1);
+            for (int64_t jp = A1(lo, k); jp <= A1(hi, k); jp++) {
+                while (wgt_gt(W, j0, jp)) j0 += 1;
+                CSET(jp, k, comb(g, CGET(j0, k - 1), ocl(O, j0, jp, k)));
+                PSET(jp, k, j0);
+                int64_t jend = jp < A1(hi, k - 1) ? jp : A1(hi, k - 1);
+                for (int64_t j = j0 + 1; j <= jend; j++) {
+                    TC c2 = comb(g, CGET(j, k - 1), ocl(O, j, jp, k));
+                    if (c2 <= CGET(jp, k)) { CSET(jp, k, c2); PSET(jp, k, j); }
+                }
+            }
+        }
+        A1(spl, K + 1) = n + 1;
+        for (int64_t k = K; k >= 1; k--) A1(spl, k) = PGET(A1(spl, k + 1), k);
+    } else {                                                // :260-314 ; columns of the window matrix = positions j'
+        part_constraints(n, K, W, lo, hi);
+        if (A1(lo, n + 1) == 0) {
+            for (int64_t k = 1; k <= K + 1; k++) A1(spl, k) = 1;
+            A1(spl, K + 1) = n + 1;
+            if (threadIdx.x == 0) *status = CP_INFEASIBLE;
+            return;
+        }
+        A1(wpos, 1) = 1;
+        for (int64_t c = 1; c <= n + 1; c++) A1(wpos, c + 1) = A1(wpos, c) + A1(hi, c) - A1(lo, c) + 1;
+        if (A1(wpos, n + 2) - 1 > cap) { if (threadIdx.x == 0) *status = CP_EUNSUPPORTED; return; }
+        int64_t j0 = 1;
+        for (int64_t jp = 1; jp <= n + 1; jp++) {
+            while (wgt_gt(W, j0, jp)) j0 += 1;
+            if (!(j0 <= jp)) { if (threadIdx.x == 0) *status = CP_EINVAL; return; }
+            TC dc = ocl(O, j0, jp, 0);
+            if (j0 == 1) { CSET(1, jp, dc); PSET(1, jp, 1); }
+            int64_t ka = (A1(lo, j0) + 1 > A1(lo, jp)) ? A1(lo, j0) + 1 : A1(lo, jp);
+            int64_t kb = (A1(hi, j0) + 1 < A1(hi, jp)) ? A1(hi, j0) + 1 : A1(hi, jp);
+            for (int64_t k = ka; k <= kb; k++) { CSET(k, jp, comb(g, CGET(k - 1, j0), dc)); PSET(k, jp, j0); }
+            for (int64_t j = j0 + 1; j <= jp; j++) {
+                dc = ocl(O, j, jp, 0);
+                ka = (A1(lo, j) + 1 > A1(lo, jp)) ? A1(lo, j) + 1 : A1(lo, jp);
+                kb = (A1(hi, j) + 1 < A1(hi, jp)) ? A1(hi, j) + 1 : A1(hi, jp);
+                for (int64_t k = ka; k <= kb; k++) {
+                    TC c2 = comb(g, CGET(k - 1, j), dc);
+                    if (c2 <= CGET(k, jp)) { CSET(k, jp, c2); PSET(k, jp, j); }
+                }
+            }
+        }
+        A1(spl, K + 1) = n + 1;
+        for (int64_t k = K; k >= 1; k--) A1(spl, k) = PGET(k, A1(spl, k + 1));
+#undef IN
+#undef AT
+#undef CGET
+#undef CSET
+#undef PGET
+#undef PSET
+    }
+    if (threadIdx.x == 0) *status = CP_OK;
+}
+
+// ------------------------------------------------------------------ host side: oracle assembly
+template <typename TC>
+struct SeqCtx {
+    HostModel<TC> HM;
+    SeqOracle<TC> O;
+    WaveletHost net, self;
+    DBuf<int32_t> asg;
+    DBuf<int64_t> pspl, hst, cursor;
+    DBuf<TC> Delta, dvec, brtab[CP_MAX_R];
+};
+
+template <typename TC>
+static void seq_oracle(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, SeqCtx<TC> &C)
+{
+    hipStream_t s = A->stream;
+    build_dev_model<TC>(mdl, C.HM, s);
+    memset(&C.O, 0, sizeof(C.O));
+    C.O.M = C.HM.d; C.O.pos = A->pos.p; C.O.row = A->row.p; C.O.n = A->n; C.O.m = A->m;
+    if (mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_COLBLOCK || mdl->kind == CP_MODEL_HYPEREDGE_CUT) {
+        ensure_net_counter(A, C.net); C.O.has_net = 1; C.O.net = C.net.d;
+    }
+    if (mdl->kind == CP_MODEL_HYPEREDGE_CUT) {
+        ensure_selfnet_counter(A, C.self); C.O.has_self = 1; C.O.self = C.self.d; C.O.lpos = A->lpos.p;
+    }
+    if (mdl->kind == CP_MODEL_BLOCK) {
+        CP_REQUIRE(Pi && Pi->spl && Pi->K >= 1, CP_EINVAL, "BlockComponentCostModel needs a SplitPartition of the rows");
+        CP_REQUIRE(Pi->spl[0] == 1 && Pi->spl[Pi->K] == A->m + 1, CP_EINVAL, "row partition does not cover 1:m");
+        int64_t K = Pi->K, m = A->m;
+        std::vector<int32_t> asg((size_t)(m > 0 ? m : 1));
+        for (int64_t k = 1; k <= K; k++) for (int64_t i = Pi->spl[k - 1]; i <= Pi->spl[k] - 1; i++) asg[(size_t)i - 1] = (int32_t)k;
+        C.asg.alloc(asg.size());
+        CP_HIP(hipMemcpyAsync(C.asg.p, asg.data(), sizeof(int32_t) * asg.size(), hipMemcpyHostToDevice, s));
+        C.pspl.alloc((size_t)K + 1);
+        CP_HIP(hipMemcpyAsync(C.pspl.p, Pi->spl, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyHostToDevice, s));
+        std::vector<int64_t> ones((size_t)K, 1);
+        C.hst.alloc((size_t)K);
+        CP_HIP(hipMemcpyAsync(C.hst.p, ones.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, s));
+        int64_t cur[2] = {1, 1};
+        C.cursor.alloc(2);
+        CP_HIP(hipMemcpyAsync(C.cursor.p, cur, sizeof(cur), hipMemcpyHostToDevice, s));
+        int R = mdl->R > 0 ? mdl->R : 1;
+        C.Delta.alloc((size_t)R * (size_t)(A->n + 1)); C.dvec.alloc((size_t)R);
+        CP_HIP(hipMemsetAsync(C.Delta.p, 0, C.Delta.bytes(), s));
+        CP_HIP(hipMemsetAsync(C.dvec.p, 0, C.dvec.bytes(), s));
+        C.O.P_asg = C.asg.p; C.O.P_spl = C.pspl.p; C.O.Kr = K; C.O.hst = C.hst.p; C.O.Delta = C.Delta.p; C.O.d = C.dvec.p; C.O.cursor = C.cursor.p;
+        for (int r = 0; r < mdl->R && r < CP_MAX_R; r++) {
+            const cp_component_t &c = mdl->beta_row[r];
+            C.O.br_const[r] = c.is_const; C.O.br_c[r] = comp_const<TC>(c); C.O.br_tab[r] = nullptr; C.O.br_len[r] = 0;
+            if (!c.is_const && c.table && c.len > 0) {
+                C.brtab[r].alloc((size_t)c.len);
+                CP_HIP(hipMemcpyAsync(C.brtab[r].p, c.table, sizeof(TC) * (size_t)c.len, hipMemcpyHostToDevice, s));
+                C.O.br_tab[r] = C.brtab[r].p; C.O.br_len[r] = c.len;
+            }
+        }
+        CP_HIP(hipStreamSynchronize(s));      // host staging vectors die at scope end
+    }
+}
+
+static SeqWeight make_weight(cp_csr_s *A, const cp_model_t *w, int64_t wi, double wf)
+{
+    SeqWeight W; memset(&W, 0, sizeof(W));
+    W.kind = w ? w->kind : CP_MODEL_FEASIBLE;
+    W.pos = A->pos.p; W.wmax_i = wi; W.wmax_f = wf;
+    if (w) { W.dtype = w->dtype; for (int i = 0; i < 3; i++) { W.pi[i] = w->p_i64[i]; W.pf[i] = w->p_f64[i]; } }
+    return W;
+}
+static bool weight_ok(const cp_model_t *w)
+{
+    return !w || w->kind == CP_MODEL_FEASIBLE || w->kind == CP_MODEL_VERTEX_COUNT || (w->kind == CP_MODEL_WORK && !w->alpha_k);
+}
+
+// unravel_chunks!(spl, n)  DynamicChunker.jl:58-75 (host: K dependent reads of a host copy)
+static int64_t unravel_chunks_host(std::vector<int64_t> &spl, int64_t n)
+{
+    int64_t K = 0, jp = n + 1, len = n + 1;
+    while (jp != 1) { int64_t j = spl[(size_t)jp - 1]; spl[(size_t)(len - K) - 1] = jp; K += 1; jp = j; }
+    spl[0] = 1;
+    for (int64_t k = 1; k <= K; k++) spl[(size_t)k] = spl[(size_t)(len - K + k) - 1];
+    return K;
+}
+
+template <typename TC>
+int32_t run_pack_dynamic(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi, double wf,
+                         int64_t *spl_out, int64_t *K_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    SeqWeight W = make_weight(A, w, wi, wf);
+    DBuf<TC> cst((size_t)n + 2);
+    DBuf<int64_t> spl((size_t)n + 2);
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    CP_HIP(hipMemsetAsync(spl.p, 0, spl.bytes(), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_dynamic<TC>), dim3(1), dim3(64), 0, s, C->O, W, cst.p, spl.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    std::vector<int64_t> h((size_t)n + 1);
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(h.data(), spl.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc != CP_OK) { set_error("pack_stripe: a single column exceeds w_max (@assert j0 < j')"); return rc; }
+    int64_t K = unravel_chunks_host(h, n);
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = h[(size_t)k];
+    *K_out = K;
+    return CP_OK;
+}
+
+template <typename TC>
+int32_t run_pack_convex(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi, double wf,
+                        int64_t *spl_out, int64_t *K_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n, cap = 2 * n + 4;
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    SeqWeight W = make_weight(A, w, wi, wf);
+    int constrained = W.kind != CP_MODEL_FEASIBLE;
+    DBuf<Ext<TC>> cst((size_t)n + 2), sig_cst((size_t)cap);
+    DBuf<int64_t> ptr((size_t)n + 2), ftr((size_t)(2 * cap)), sig_j((size_t)cap), sig_jp((size_t)cap), sig_ptr((size_t)cap);
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    CP_HIP(hipMemsetAsync(sig_ptr.p, 0, sig_ptr.bytes(), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_convex<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, cst.p, ptr.p, ftr.p,
+                           sig_j.p, sig_jp.p, sig_ptr.p, sig_cst.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    std::vector<int64_t> h((size_t)n + 2);
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(h.data(), ptr.p, sizeof(int64_t) * (size_t)(n + 2), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc != CP_OK) { set_error("ConvexTotalChunker: a single column exceeds w_max"); return rc; }
+    std::vector<int64_t> sp((size_t)n + 1);
+    for (int64_t jp = 1; jp <= n + 1; jp++) sp[(size_t)jp - 1] = h[(size_t)jp];
+    int64_t K = unravel_chunks_host(sp, n);
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = sp[(size_t)k];
+    *K_out = K;
+    return CP_OK;
+}
+
+template <typename TC>
+int32_t run_partition_convex(cp_csr_s *A, int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi,
+                             double wf, int64_t *spl_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n, cap = 2 * n + 4;
+    SeqWeight W = make_weight(A, w, wi, wf);
+    int constrained = W.kind != CP_MODEL_FEASIBLE;
+    if (!constrained && K == 1) { spl_out[0] = 1; spl_out[1] = n + 1; return CP_OK; }         // :32-34
+    CP_REQUIRE((double)K * (double)(n + 2) < 4e8, CP_EUNSUPPORTED, "ConvexTotalSplitter tables exceed the device budget");
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    DBuf<Ext<TC>> cst((size_t)K * (size_t)(n + 2)), sig_cst((size_t)cap);
+    DBuf<int64_t> ptr((size_t)K * (size_t)(n + 2)), jlo((size_t)K), jhi((size_t)K), ftr((size_t)(2 * cap)), sig_j((size_t)cap),
+        sig_jp((size_t)cap), sig_ptr((size_t)cap), spl((size_t)K + 1);
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    CP_HIP(hipMemsetAsync(sig_ptr.p, 0, sig_ptr.bytes(), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition_convex<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, K, cst.p, ptr.p, jlo.p,
+                           jhi.p, ftr.p, sig_j.p, sig_jp.p, sig_ptr.p, sig_cst.p, spl.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(spl_out, spl.p, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc == CP_EINVAL) set_error("ConvexTotalSplitter: a single column exceeds w_max");
+    return rc;
+}
+
+template <typename TC>
+int32_t run_dyn_constrained(cp_csr_s *A, int64_t K, int32_t g, int32_t order, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                            const cp_model_t *w, int64_t wi, double wf, int64_t *spl_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    // DynamicSplitter.jl:279 rebuilds f WITHOUT the row partition in the chunker loop order
+    if (order == CP_ORDER_CHUNKER && mdl->kind == CP_MODEL_BLOCK) { set_error("no oracle_stripe(BlockComponentCostModel, A) without a row partition (DynamicSplitter.jl:279)"); return CP_EUNSUPPORTED; }
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, order == CP_ORDER_CHUNKER ? nullptr : Pi, *C);
+    SeqWeight W = make_weight(A, w, wi, wf);
+    int64_t ncol = order == CP_ORDER_SPLITTER ? K : n + 1;
+    int64_t cap = (int64_t)2e8;
+    double est = (double)K * (double)(n + 1);
+    if (est < (double)cap) cap = (int64_t)est + 16;
+    DBuf<int64_t> lo((size_t)ncol + 1), hi((size_t)ncol + 1), wpos((size_t)ncol + 2), pv((size_t)cap), spl((size_t)K + 1);
+    DBuf<TC> cv((size_t)cap);
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    CP_HIP(hipMemsetAsync(pv.p, 0, pv.bytes(), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dyn_constrained<TC>), dim3(1), dim3(64), 0, s, C->O, W, K, g, order, lo.p, hi.p, wpos.p, cv.p,
+                           pv.p, cap, spl.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(spl_out, spl.p, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc == CP_EUNSUPPORTED) set_error("constrained DP window tables exceed the device budget");
+    return rc;
+}
+
+// ocl(j, j', k) for a batch, evaluated in order by the stateful oracle (BlockComponentCostStepOracle)
+template <typename TC>
+__global__ void __launch_bounds__(64) k_seq_eval(SeqOracle<TC> O, int64_t nq, const int64_t *__restrict__ j, const int64_t *__restrict__ jp,
+                                                 const int64_t *__restrict__ k, TC *__restrict__ out)
+{
+    for (int64_t t = 0; t < nq; t++) out[t] = ocl(O, j[t], jp[t], k ? k[t] : (int64_t)0);
+}
+
+template <typename TC>
+int32_t run_seq_eval(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int64_t *j, const int64_t *jp,
+                     const int64_t *k, TC *out)
+{
+    hipStream_t s = A->stream;
+    if (nq <= 0) return CP_OK;
+    for (int64_t t = 0; t < nq; t++) CP_REQUIRE(j[t] >= 1 && jp[t] >= j[t] && jp[t] <= A->n + 1, CP_EINVAL, "oracle query needs 1 <= j <= j' <= n+1");
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    DBuf<int64_t> dj((size_t)nq), djp((size_t)nq), dk;
+    DBuf<TC> dout((size_t)nq);
+    CP_HIP(hipMemcpyAsync(dj.p, j, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+    CP_HIP(hipMemcpyAsync(djp.p, jp, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s));
+    if (k) { dk.alloc((size_t)nq); CP_HIP(hipMemcpyAsync(dk.p, k, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s)); }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seq_eval<TC>), dim3(1), dim3(64), 0, s, C->O, nq, dj.p, djp.p, k ? dk.p : nullptr, dout.p);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipMemcpyAsync(out, dout.p, sizeof(TC) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    return CP_OK;
+}
+template int32_t run_seq_eval<int64_t>(cp_csr_s *, const cp_model_t *, const cp_rowpart_t *, int64_t, const int64_t *, const int64_t *, const int64_t *, int64_t *);
+template int32_t run_seq_eval<double>(cp_csr_s *, const cp_model_t *, const cp_rowpart_t *, int64_t, const int64_t *, const int64_t *, const int64_t *, double *);
+
+template int32_t run_dyn_constrained<int64_t>(cp_csr_s *, int64_t, int32_t, int32_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *);
+template int32_t run_dyn_constrained<double>(cp_csr_s *, int64_t, int32_t, int32_t, const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double, int64_t *);
+
+}  // namespace cpk
+
+using namespace cpk;
+
+static bool seq_model_ok(const cp_model_t *m)
+{
+    return m && (m->kind == CP_MODEL_WORK || m->kind == CP_MODEL_CONNECTIVITY || m->kind == CP_MODEL_HYPEREDGE_CUT ||
+                 m->kind == CP_MODEL_COLBLOCK || m->kind == CP_MODEL_BLOCK) && (m->dtype == CP_I64 || m->dtype == CP_F64);
+}
+
+extern "C" {
+
+int32_t cp_pack_dynamic(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64,
+                        double wmax_f64, int64_t *spl_out, int64_t *K_out)
+{
+    try {
+        CP_REQUIRE(A && spl_out && K_out && seq_model_ok(model) && weight_ok(weight), CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_pack_dynamic<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+        return run_pack_dynamic<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+int32_t cp_pack_convex(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64,
+                       double wmax_f64, int64_t *spl_out, int64_t *K_out)
+{
+    try {
+        CP_REQUIRE(A && spl_out && K_out && seq_model_ok(model) && weight_ok(weight), CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_pack_convex<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+        return run_pack_convex<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+int32_t cp_partition_convex(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight,
+                            int64_t wmax_i64, double wmax_f64, int64_t *spl_out)
+{
+    try {
+        CP_REQUIRE(A && spl_out && K >= 1 && seq_model_ok(model) && weight_ok(weight), CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_partition_convex<int64_t>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+        return run_partition_convex<double>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+}  // extern "C"

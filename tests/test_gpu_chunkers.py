@@ -1,0 +1,82 @@
+"""GPU parity of the sequential partitioners (csrc/seq.hip) against the CPU oracle: bit-exact split
+vectors for pack_stripe(DynamicTotalChunker / ConvexTotalChunker), ConvexTotalSplitter, the
+ConstrainedCost DP variants, and the block-cost oracle."""
+import numpy as np
+import pytest
+
+from util import cp, sprand, golden_matrices, suitesparse_shaped, banded
+
+pytestmark = pytest.mark.gpu
+
+
+def mats(seed):
+    rng = np.random.default_rng(seed)
+    out = [sprand(m, n, p, rng) for (m, n, p) in [(1, 1, 0.5), (2, 3, 0.5), (4, 8, 0.3), (8, 8, 0.3), (8, 16, 0.3), (12, 31, 0.15),
+                                                  (20, 40, 0.1), (30, 65, 0.08)]]
+    g = golden_matrices()
+    out += [g["LPnetlib/lpi_itest6"], g["Pajek/GD99_c"], g["LPnetlib/lp_blend"]]
+    out += [suitesparse_shaped(200, 4, 7), banded(150, 3, 0.5, 3)]
+    return out
+
+
+FS = [cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(-0.5, 0.0, 0.0, 1.0),
+      cp.AffineWorkModel(0, 0, 0), cp.AffineWorkModel(0, 10, 1), cp.AffineHyperedgeCutModel(0, 1, 1, 1, 3),
+      cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w)]
+
+
+def test_pack_dynamic(hip, orc):
+    for A in mats(1):
+        for f in FS:
+            variants = [f] + [cp.ConstrainedCost(f, cp.VertexCount(), w) for w in (2, 4, 8)] + [cp.ConstrainedCost(f, cp.AffineWorkModel(0, 1, 0), 4)]
+            for fc in variants:
+                got = cp.pack_stripe(A, cp.DynamicTotalChunker(fc), backend=hip)
+                want = cp.pack_stripe(A, cp.DynamicTotalChunker(fc), backend=orc)
+                assert got == want, (A, f.kind)
+                assert cp.total_value(A, got, f, backend=hip) == cp.total_value(A, want, f, backend=orc)
+
+
+def test_pack_convex(hip, orc):
+    for A in mats(2):
+        for f in FS:
+            variants = [f] + [cp.ConstrainedCost(f, cp.VertexCount(), w) for w in (2, 4, 8)] + [cp.ConstrainedCost(f, cp.AffineWorkModel(0, 1, 0), 4)]
+            for fc in variants:
+                got = cp.pack_stripe(A, cp.ConvexTotalChunker(fc), backend=hip)
+                want = cp.pack_stripe(A, cp.ConvexTotalChunker(fc), backend=orc)
+                assert got == want, (A, f.kind)
+
+
+def test_partition_convex_and_constrained_dp(hip, orc):
+    for A in mats(3):
+        for K in (1, 2, 3, 4, 8):
+            for f in FS[:5]:
+                got = cp.partition_stripe(A, K, cp.ConvexTotalSplitter(f), backend=hip)
+                want = cp.partition_stripe(A, K, cp.ConvexTotalSplitter(f), backend=orc)
+                assert got == want, (A, K, f.kind)
+                for w_max in (2, 4, 8):
+                    fc = cp.ConstrainedCost(f, cp.AffineWorkModel(0, 1, 0), w_max)
+                    for meth in (cp.ConvexTotalSplitter(fc), cp.DynamicTotalSplitter(fc), cp.DynamicBottleneckSplitter(fc),
+                                 cp.DynamicTotalChunker(fc), cp.DynamicBottleneckChunker(fc)):
+                        got = cp.partition_stripe(A, K, meth, backend=hip)
+                        want = cp.partition_stripe(A, K, meth, backend=orc)
+                        assert got == want, (A, K, f.kind, w_max, type(meth).__name__)
+
+
+def test_block_costs(hip, orc):
+    """BlockComponentCostStepOracle on the device: total_value and width-limited chunking (test_Costs.jl:106-122,
+    test_Partitioners.jl:225-248)."""
+    rng = np.random.default_rng(6)
+    for m in (3, 8, 17, 30):
+        A = sprand(m, m, 0.2, rng)
+        for u in (1, 2, 4):
+            Pi = cp.pack_stripe(A, cp.EquiChunker(u))
+            for mdl in (cp.BlockComponentCostModel(0, 0, (2, lambda x: x), (2, lambda x: 2 * x)),
+                        cp.BlockComponentCostModel(lambda x: x, lambda x: 3 * x, (10, lambda x: x), (2, lambda x: 2 * x)),
+                        cp.BlockComponentCostModel(1, 3, (1,), (1,))):
+                for w in (1, 2, 4):
+                    Phi = cp.pack_stripe(A, cp.EquiChunker(w))
+                    assert cp.total_value(A, Phi, mdl, Pi, backend=hip) == cp.total_value(A, Phi, mdl, Pi, backend=orc)
+                f = cp.ConstrainedCost(mdl, cp.VertexCount(), 4)
+                got = cp.pack_stripe(A, cp.DynamicTotalChunker(f), Pi, backend=hip)
+                want = cp.pack_stripe(A, cp.DynamicTotalChunker(f), Pi, backend=orc)
+                assert got == want
+                assert np.all(np.diff(got.spl) <= 4)
