@@ -47,3 +47,19 @@ def test_counts_match_oracle_on_larger_inputs(hip, orc):
             got = f(A, backend=hip)(a, b)
             want = f(A, backend=orc)(a, b)
             assert np.array_equal(got, want), kind
+
+
+def test_partwise_matches_oracle(hip, orc):
+    """partwise(A, Pi) on the device == the reference's two-pass counting sort (PartwiseCounts.jl:1-60)."""
+    rng = np.random.default_rng(21)
+    cases = [(sprand(8, 9, 0.4, rng), 3), (sprand(20, 15, 0.3, rng), 4), (sprand(7, 7, 0.5, rng), 1), (sprand(5, 6, 0.0, rng), 2),
+             (sprand(30, 40, 0.1, rng), 7), (golden_matrices()["LPnetlib/lp_blend"], 5), (suitesparse_shaped(2000, 5, 3), 16)]
+    for A, K in cases:
+        asg = rng.integers(1, K + 1, A.m)
+        if K >= 3:
+            asg[asg == 2] = 1                      # leave a part empty
+        got = hip.partwise(A, K, asg)
+        want = orc.partwise(A, K, asg)
+        assert got[0] == want[0]
+        for a, b in zip(got[1:], want[1:]):
+            assert np.array_equal(a, b)
