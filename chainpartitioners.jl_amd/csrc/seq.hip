@@ -36,6 +36,8 @@ struct SeqOracle {
     TC *Delta;                 // R x (n+1), column-major
     TC *d;                     // R
     int64_t *cursor;           // [0] = ocl.j, [1] = ocl.j'
+    // optional table of every pair inside a width window: Ftab[j' * (Wc+1) + (j'-j)] = f(j, j') for j'-j <= Wc
+    const TC *Ftab; int64_t Wc;
     // block-row components
     int32_t br_const[CP_MAX_R]; TC br_c[CP_MAX_R]; const TC *br_tab[CP_MAX_R]; int64_t br_len[CP_MAX_R];
 };
@@ -85,12 +87,39 @@ template <typename TC>
 __device__ TC ocl(const SeqOracle<TC> &O, int64_t j, int64_t jp, int64_t k)
 {
     if (O.M.kind == CP_MODEL_BLOCK) return block_call(O, j, jp);
+    if (O.Ftab && jp - j <= O.Wc) return O.Ftab[jp * (O.Wc + 1) + (jp - j)];
     int64_t p = j - 1, r = jp - 1;
     int64_t np = O.pos[r] - O.pos[p];
     int64_t nn = 0, nl = 0;
     if (O.has_net) nn = np - wt_count_le(O.net, O.n - p, O.pos[r]);
     if (O.has_self) nl = wt_count_le(O.self, O.n - p, O.lpos[r]);
     return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, nn, nl);
+}
+
+// every pair (j, j') with j' - j <= Wc, one thread per j': walks the candidate j downwards with the same link-array
+// left steps as the DP (nets += #{q in column : next[q] >= r}; self nets += #{rows first == column, last < r})
+template <typename TC>
+__global__ void __launch_bounds__(256) k_window_table(DevModel<TC> M, int64_t n, int64_t Wc, const int64_t *__restrict__ pos,
+                                                      const int32_t *__restrict__ next, const int64_t *__restrict__ fpos,
+                                                      const int32_t *__restrict__ flast, TC *__restrict__ F)
+{
+    int64_t jp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;       // 1-based j'
+    if (jp > n + 1) return;
+    int64_t r = jp - 1;
+    TC alpha = M.p[CP_P_ALPHA];
+    bool nets = M.kind == CP_MODEL_CONNECTIVITY || M.kind == CP_MODEL_COLBLOCK || M.kind == CP_MODEL_HYPEREDGE_CUT;
+    bool self = M.kind == CP_MODEL_HYPEREDGE_CUT;
+    int64_t nn = 0, nl = 0;
+    TC *row = F + jp * (Wc + 1);
+    row[0] = dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0);
+    int32_t rr = (int32_t)r;
+    for (int64_t d = 1; d <= Wc; d++) {
+        int64_t p = r - d;
+        if (p < 0) break;
+        if (nets) for (int64_t q = pos[p]; q < pos[p + 1]; q++) nn += (next[q] >= rr);
+        if (self) for (int64_t q = fpos[p]; q < fpos[p + 1]; q++) nl += (flast[q] < rr);
+        row[d] = dm_apply(M, alpha, d, pos[r] - pos[p], nn, nl);
+    }
 }
 
 // ------------------------------------------------------------------ weights of ConstrainedCost
@@ -457,7 +486,7 @@ struct SeqCtx {
     WaveletHost net, self;
     DBuf<int32_t> asg;
     DBuf<int64_t> pspl, hst, cursor;
-    DBuf<TC> Delta, dvec, brtab[CP_MAX_R];
+    DBuf<TC> Delta, dvec, brtab[CP_MAX_R], ftab;
 };
 
 template <typename TC>
@@ -507,6 +536,24 @@ static void seq_oracle(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *P
     }
 }
 
+// pairs inside a VertexCount window come from a table built in one parallel pass over the link arrays
+template <typename TC>
+static void seq_window_table(cp_csr_s *A, const cp_model_t *mdl, const cp_model_t *w, int64_t wmax, SeqCtx<TC> &C)
+{
+    if (!w || w->kind != CP_MODEL_VERTEX_COUNT || mdl->kind == CP_MODEL_BLOCK || mdl->alpha_k || wmax < 1) return;
+    int64_t n = A->n, Wc = wmax;
+    if ((double)(n + 2) * (double)(Wc + 1) > 6e8) return;
+    hipStream_t s = A->stream;
+    ensure_links(A);
+    if (mdl->kind == CP_MODEL_HYPEREDGE_CUT) ensure_self(A);
+    C.ftab.alloc((size_t)(n + 2) * (size_t)(Wc + 1));
+    ProfScope ps(PROF_CHUNK, s, 0.0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_window_table<TC>), dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, C.HM.d, n, Wc, A->pos.p,
+                       A->next.p, A->fpos.p, A->flast.p, C.ftab.p);
+    CP_HIP(hipGetLastError());
+    C.O.Ftab = C.ftab.p; C.O.Wc = Wc;
+}
+
 static SeqWeight make_weight(cp_csr_s *A, const cp_model_t *w, int64_t wi, double wf)
 {
     SeqWeight W; memset(&W, 0, sizeof(W));
@@ -538,6 +585,7 @@ int32_t run_pack_dynamic(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t 
     int64_t n = A->n;
     std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
     seq_oracle<TC>(A, mdl, Pi, *C);
+    seq_window_table<TC>(A, mdl, w, wi, *C);
     SeqWeight W = make_weight(A, w, wi, wf);
     DBuf<TC> cst((size_t)n + 2);
     DBuf<int64_t> spl((size_t)n + 2);
@@ -570,6 +618,7 @@ int32_t run_pack_convex(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *
     int64_t n = A->n, cap = 2 * n + 4;
     std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
     seq_oracle<TC>(A, mdl, Pi, *C);
+    seq_window_table<TC>(A, mdl, w, wi, *C);
     SeqWeight W = make_weight(A, w, wi, wf);
     int constrained = W.kind != CP_MODEL_FEASIBLE;
     DBuf<Ext<TC>> cst((size_t)n + 2), sig_cst((size_t)cap);
