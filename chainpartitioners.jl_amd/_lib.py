@@ -14,7 +14,7 @@ import numpy as np
 from . import models as M
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchainpart.so")
+LIB_PATH = os.environ.get("CP_LIB_PATH") or os.path.join(_HERE, "libchainpart.so")   # CP_LIB_PATH: A/B builds only
 
 SYMBOLS = [
     "cp_last_error", "cp_version", "cp_device_count", "cp_csr_create", "cp_csr_create_device", "cp_csr_destroy",

@@ -114,6 +114,7 @@ static bool fast_total_ok(const cp_model_t *m)
     auto P = [&](int i) { return m->dtype == CP_I64 ? (double)m->p_i64[i] : m->p_f64[i]; };
     if (m->kind == CP_MODEL_WORK) return true;
     if (m->kind == CP_MODEL_CONNECTIVITY) return P(CP_P_NET) >= 0;
+    if (m->kind == CP_MODEL_HYPEREDGE_CUT) return P(CP_P_CUT_NET) >= 0 && P(CP_P_SELF_NET) <= P(CP_P_CUT_NET);
     return false;
 }
 

@@ -281,7 +281,7 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipMemcpyAsync(&tot, A->fpos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     A->nrows_nonempty = tot;
-    A->flast.alloc((size_t)(tot > 0 ? tot : 1)); A->lfirst.alloc((size_t)(tot > 0 ? tot : 1));
+    A->flast.alloc((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.alloc((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,

@@ -52,6 +52,9 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 // ------------------------------------------------------------------ right part: row-major threshold counts
 // cr[b][r] = #{q in columns [r-2^tau, r) : prev[q] < opt[b][r-2^tau]} for every set bit b > tau of r.
 // Small ranges: one lane per row (tau <= 3).
+// `ge` selects the comparison: 0: link < threshold (nets: prev[q] < B); 1: link >= threshold (self nets: first >= B
+// over the rows bucketed by their LAST column).
+template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
                                                      int32_t *__restrict__ cr)
@@ -64,14 +67,14 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
         bool on = b > tau && b < nbits && ((r >> b) & 1);
-        thr[b] = on ? opt[(int64_t)b * n1 + rL] : INT32_MIN;
+        thr[b] = on ? opt[(int64_t)b * n1 + rL] : (ge ? INT32_MAX : INT32_MIN);
         cnt[b] = 0;
     }
     int64_t q0 = pos[rL], q1 = pos[r];
     for (int64_t q = q0; q < q1; q++) {
         int32_t v = prev[q];
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) cnt[b] += (v < thr[b]);
+        for (int b = 0; b < NBMAX; b++) cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++)
@@ -79,6 +82,7 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
 }
 
 // Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
+template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t nrows, int chunks_per_row, int ch_cols,
                                                     const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
                                                     const int32_t *__restrict__ opt, int32_t *__restrict__ cr)
@@ -97,14 +101,14 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
         bool on = b > tau && b < nbits && ((r >> b) & 1);
-        thr[b] = on ? opt[(int64_t)b * n1 + rL] : INT32_MIN;       // wave-uniform address
+        thr[b] = on ? opt[(int64_t)b * n1 + rL] : (ge ? INT32_MAX : INT32_MIN);       // wave-uniform address
         cnt[b] = 0;
     }
     int64_t q0 = pos[c0], q1 = pos[c1];
     for (int64_t q = q0 + lane; q < q1; q += 64) {
         int32_t v = prev[q];
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) cnt[b] += (v < thr[b]);
+        for (int b = 0; b < NBMAX; b++) cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
@@ -126,15 +130,16 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
 __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                int32_t *__restrict__ cr, int zero_cr_only,
                                                int32_t *__restrict__ tB, int32_t *__restrict__ tS0, int32_t *__restrict__ tr,
-                                               uint8_t *__restrict__ tb, int32_t *__restrict__ len)
+                                               uint8_t *__restrict__ tb, int32_t *__restrict__ len,
+                                               const int32_t *__restrict__ nlopt, int32_t *__restrict__ crl, int32_t *__restrict__ tS0l)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R.ntask) return;
     int64_t r; int b;
     decode_task(R, t, r, b);
     int64_t n1 = R.n + 1;
-    if (zero_cr_only) { cr[(int64_t)b * n1 + r] = 0; return; }
-    int64_t B, a, S0;
+    if (zero_cr_only) { cr[(int64_t)b * n1 + r] = 0; if (crl) crl[(int64_t)b * n1 + r] = 0; return; }
+    int64_t B, a, S0, S0l = 0;
     if (R.isA) {
         B = r; a = r - ((int64_t)1 << b); S0 = 0;
     } else {
@@ -142,19 +147,28 @@ __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__res
         int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
         B = opt[(int64_t)b * n1 + rL];
         S0 = (int64_t)nnopt[(int64_t)b * n1 + rL] + cr[(int64_t)b * n1 + r];
+        if (tS0l) S0l = (int64_t)nlopt[(int64_t)b * n1 + rL] + crl[(int64_t)b * n1 + r];
         a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
         if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
     }
     tB[t] = (int32_t)B; tS0[t] = (int32_t)S0; tr[t] = (int32_t)r; tb[t] = (uint8_t)b;
     len[t] = (int32_t)(1 + (B - a));
+    if (tS0l) tS0l[t] = (int32_t)S0l;
 }
 
 // ------------------------------------------------------------------ wave-level segmented scans (64 lanes)
-template <typename TC>
-struct Best { TC v; int32_t p; int32_t nn; };
+template <typename TC, bool HYP> struct Best;
+template <typename TC> struct Best<TC, false> { TC v; int32_t p; int32_t nn; };                         // 16 bytes
+template <typename TC> struct Best<TC, true> { TC v; int32_t p; int32_t nn; int32_t nl; int32_t _pad; };
+template <typename TC> __device__ __forceinline__ void best_clear(Best<TC, false> &b) { b.v = (TC)0; b.p = -1; b.nn = 0; }
+template <typename TC> __device__ __forceinline__ void best_clear(Best<TC, true> &b) { b.v = (TC)0; b.p = -1; b.nn = 0; b.nl = 0; b._pad = 0; }
+template <typename TC> __device__ __forceinline__ int32_t best_nl(const Best<TC, false> &) { return 0; }
+template <typename TC> __device__ __forceinline__ int32_t best_nl(const Best<TC, true> &b) { return b.nl; }
+template <typename TC> __device__ __forceinline__ void best_set_nl(Best<TC, false> &, int32_t) {}
+template <typename TC> __device__ __forceinline__ void best_set_nl(Best<TC, true> &b, int32_t v) { b.nl = v; }
 
-template <typename TC>
-__device__ __forceinline__ Best<TC> better(const Best<TC> &a, const Best<TC> &b)   // a is earlier (larger p): wins ties
+template <typename TC, bool HYP>
+__device__ __forceinline__ Best<TC, HYP> better(const Best<TC, HYP> &a, const Best<TC, HYP> &b)   // a is earlier (larger p): wins ties
 {
     if (a.p < 0) return b;
     if (b.p < 0) return a;
@@ -185,15 +199,17 @@ __device__ __forceinline__ void wave_segsum(int32_t &v, int &f, int lane)
     }
 }
 
-template <typename TC>
-__device__ __forceinline__ void wave_segmin(Best<TC> &x, int &f, int lane)
+template <typename TC, bool HYP>
+__device__ __forceinline__ void wave_segmin(Best<TC, HYP> &x, int &f, int lane)
 {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        Best<TC> p;
+        Best<TC, HYP> p;
+        best_clear(p);
         p.v = shfl_up64(x.v, o);
         p.p = __shfl_up(x.p, o);
         p.nn = __shfl_up(x.nn, o);
+        if (HYP) best_set_nl(p, __shfl_up(best_nl(x), o));
         int pf = __shfl_up(f, o);
         if (lane >= o) { if (!f) x = better(p, x); f |= pf; }
     }
@@ -229,103 +245,55 @@ __device__ __forceinline__ void load_tile_tasks(const int64_t *__restrict__ offs
     }
 }
 
-// ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
-template <typename TC>
-__global__ void __launch_bounds__(256) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ offs,
-                                               const int32_t *__restrict__ tB, const int32_t *__restrict__ tS0,
-                                               const int32_t *__restrict__ tr, const uint8_t *__restrict__ tb,
-                                               const int64_t *__restrict__ pos, const int32_t *__restrict__ next,
-                                               const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                               int32_t *__restrict__ opt, int32_t *__restrict__ nnopt,
-                                               int32_t *__restrict__ loc, int32_t *__restrict__ tileS,
-                                               Best<TC> *__restrict__ partR, int64_t *__restrict__ taskR,
-                                               const int64_t *__restrict__ tile_t0, int dbg)
+// ------------------------------------------------------------------ cooperative column counts
+// Every lane owns one column-like range [s, en) of `arr` and a threshold; lanes whose ranges are adjacent and
+// descending form a run whose entries [q_lo, q_hi) are read as aligned 16-byte-per-lane loads (1 KiB per wave
+// instruction, two in flight); position x + 4*lane' + j sits in component j of lane'.  Returns, per lane,
+// #{entries of its range with  v >= thr (GE)  or  v < thr (!GE)}.  One ballot pass per distinct threshold
+// (= task) touching a 256-entry block.
+template <bool GE>
+__device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, int64_t s, int64_t en, int32_t thr, bool valid, int lane)
 {
-    __shared__ int64_t s_off_all[4][LT + 2];
-    __shared__ unsigned long long s_hd_all[4][LT / 64];
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    int64_t tile_start = tile * LT;
-    bool active = tile_start < T;
-    int64_t *s_off = s_off_all[wave];
-    unsigned long long *s_hd = s_hd_all[wave];
-    int64_t t0 = active ? tile_t0[tile] : 0; int cnt;
-    load_tile_tasks(offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
-    __syncthreads();
-    if (!active) return;
-    // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
-    int head_at0 = (s_off[0] == tile_start) ? 1 : 0;
-    int hd_before = 0;                                  // heads in the groups already processed
-    int64_t n1 = R.n + 1;
-    int64_t tile_last = tile_start + LT - 1;
-    if (tile_last > T - 1) tile_last = T - 1;
-
-    constexpr int NG = LT / 64;
-    int carryF = 0; int32_t carryS = 0;               // segmented-sum state across the groups of the tile
-    Best<TC> bcarry; bcarry.p = -1; bcarry.nn = 0; bcarry.v = (TC)0;
-    for (int g = 0; g < NG; g++) {
-        int64_t e = tile_start + g * 64 + lane;
-        bool valid = e <= tile_last;
-        int64_t t = 0, i = 0, r = 0, B = 0, p = -1, toff = 0, seg_last = -1, s = 0, en = 0, posr = 0;
-        int32_t s0 = 0; TC wp = (TC)0;
-        unsigned long long hmask = s_hd[g];
-        if (valid) {
-            int li = hd_before + __popcll(hmask & ((2ull << lane) - 1)) - head_at0;
-            t = t0 + li;
-            toff = s_off[li];
-            seg_last = ((li + 1 < cnt) ? s_off[li + 1] : offs[t + 1]) - 1;
-            i = e - toff;
-            r = tr[t]; B = tB[t]; s0 = tS0[t];
-            p = B - i;
-            if (i == 0) { s = en = pos[B]; }
-            else { s = pos[p]; en = pos[p + 1]; }
-            posr = pos[r];
-            wp = W[p];
-            if (i == 0 && R.isA) p = -1;              // round A: element 0 (p = r) is not a candidate
-        }
-        hd_before += __popcll(hmask);
-        int32_t thr = valid ? (int32_t)r : INT32_MAX;
-        // ---- cooperative streaming: a run = lanes whose nonzero ranges are adjacent and descending.
-        // The run's nonzeros [q_lo, q_hi) are read as aligned 16-byte-per-lane loads (1 KiB per wave instruction,
-        // two in flight); position x + 4*lane' + j sits in component j of lane'.
-        int64_t prev_s = shfl_up64(s, 1);
-        int prev_valid = __shfl_up((int)valid, 1);
-        bool cont = valid && lane > 0 && prev_valid && (en == prev_s);
-        unsigned long long heads = __ballot(valid && !cont);
-        unsigned long long vm = __ballot(valid);
-        int32_t d = 0;
-        while (heads) {
-            int h0 = __ffsll((long long)heads) - 1;
-            heads &= heads - 1;
-            int h1 = heads ? (__ffsll((long long)heads) - 1) : 64;
-            unsigned long long inrun = vm & (h1 == 64 ? ~0ull : ((1ull << h1) - 1)) & ~((1ull << h0) - 1);
-            int hl = 63 - __clzll((long long)inrun);      // last valid lane of the run
-            int64_t q_hi = shfl64(en, h0), q_lo = shfl64(s, hl);
-            bool mine = lane >= h0 && lane <= hl && en > s;
-            for (int64_t x = q_lo & ~(int64_t)3; x < q_hi && !(dbg & 4); x += 512) {
-                int4 v0 = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN), v1 = v0;
-                int64_t b0 = x + 4 * lane, b1 = b0 + 256;
-                if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(next + b0);     // next is padded by 4 entries
-                if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(next + b1);
+    int64_t prev_s = shfl_up64(s, 1);
+    int prev_valid = __shfl_up((int)valid, 1);
+    bool cont = valid && lane > 0 && prev_valid && (en == prev_s);
+    unsigned long long heads = __ballot(valid && !cont);
+    unsigned long long vm = __ballot(valid);
+    int32_t d = 0;
+    const int32_t FILL = GE ? INT32_MIN : INT32_MAX;          // never counted
+    while (heads) {
+        int h0 = __ffsll((long long)heads) - 1;
+        heads &= heads - 1;
+        int h1 = heads ? (__ffsll((long long)heads) - 1) : 64;
+        unsigned long long inrun = vm & (h1 == 64 ? ~0ull : ((1ull << h1) - 1)) & ~((1ull << h0) - 1);
+        int hl = 63 - __clzll((long long)inrun);          // last valid lane of the run
+        int64_t q_hi = shfl64(en, h0), q_lo = shfl64(s, hl);
+        bool mine = lane >= h0 && lane <= hl && en > s;
+        for (int64_t x = q_lo & ~(int64_t)3; x < q_hi; x += 512) {
+            int4 v0 = make_int4(FILL, FILL, FILL, FILL), v1 = v0;
+            int64_t b0 = x + 4 * lane, b1 = b0 + 256;
+            if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(arr + b0);        // arrays are padded by 8 entries
+            if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(arr + b1);
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    int64_t xc = x + c * 256;
-                    if (xc >= q_hi) break;                // wave-uniform
-                    int4 v = c ? v1 : v0;
-                    int64_t pb = xc + 4 * lane;           // position of component 0
-                    bool in0 = pb >= q_lo && pb < q_hi, in1 = pb + 1 >= q_lo && pb + 1 < q_hi;
-                    bool in2 = pb + 2 >= q_lo && pb + 2 < q_hi, in3 = pb + 3 >= q_lo && pb + 3 < q_hi;
-                    bool ov = mine && s < xc + 256 && en > xc;
-                    // this lane's column covers positions [a0, a1) of the block: lanes [lo_j, hi_j) of component j
-                    int a0 = ov ? (int)((s > xc ? s : xc) - xc) : 0, a1 = ov ? (int)((en < xc + 256 ? en : xc + 256) - xc) : 0;
-                    unsigned long long rem = __ballot(ov);
-                    while (rem) {                         // one pass per distinct threshold (= task) touching the block
-                        int l = __ffsll((long long)rem) - 1;
-                        int32_t thr_u = __shfl(thr, l);
-                        unsigned long long m0 = __ballot(in0 && v.x >= thr_u), m1 = __ballot(in1 && v.y >= thr_u);
-                        unsigned long long m2 = __ballot(in2 && v.z >= thr_u), m3 = __ballot(in3 && v.w >= thr_u);
-                        bool same = ov && thr == thr_u;
-                        if (same) {
+            for (int c = 0; c < 2; c++) {
+                int64_t xc = x + c * 256;
+                if (xc >= q_hi) break;                    // wave-uniform
+                int4 v = c ? v1 : v0;
+                int64_t pb = xc + 4 * lane;               // position of component 0
+                bool in0 = pb >= q_lo && pb < q_hi, in1 = pb + 1 >= q_lo && pb + 1 < q_hi;
+                bool in2 = pb + 2 >= q_lo && pb + 2 < q_hi, in3 = pb + 3 >= q_lo && pb + 3 < q_hi;
+                bool ov = mine && s < xc + 256 && en > xc;
+                // this lane's range covers positions [a0, a1) of the block: lanes [lo_j, hi_j) of component j
+                int a0 = ov ? (int)((s > xc ? s : xc) - xc) : 0, a1 = ov ? (int)((en < xc + 256 ? en : xc + 256) - xc) : 0;
+                unsigned long long rem = __ballot(ov);
+                while (rem) {                             // one pass per distinct threshold touching the block
+                    int l = __ffsll((long long)rem) - 1;
+                    int32_t tu = __shfl(thr, l);
+                    unsigned long long m0, m1, m2, m3;
+                    if (GE) { m0 = __ballot(in0 && v.x >= tu); m1 = __ballot(in1 && v.y >= tu); m2 = __ballot(in2 && v.z >= tu); m3 = __ballot(in3 && v.w >= tu); }
+                    else    { m0 = __ballot(in0 && v.x < tu);  m1 = __ballot(in1 && v.y < tu);  m2 = __ballot(in2 && v.z < tu);  m3 = __ballot(in3 && v.w < tu); }
+                    bool same = ov && thr == tu;
+                    if (same) {
 #define CP_CNT(mj, j)                                                                                   \
     {                                                                                                   \
         int lo_ = (a0 - (j) + 3) >> 2, hi_ = (a1 - (j) + 3) >> 2;                                       \
@@ -336,88 +304,175 @@ __global__ void __launch_bounds__(256) k_lpass(RoundDesc R, int64_t T, const int
             d += __popcll((mj) & mm_);                                                                  \
         }                                                                                               \
     }
-                            CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
+                        CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
 #undef CP_CNT
-                        }
-                        rem &= ~__ballot(same);
                     }
+                    rem &= ~__ballot(same);
                 }
             }
         }
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
+// HYP: hyperedge-cut costs carry a second count (self nets): rows bucketed by their FIRST column (fpos / flast),
+// a column p joining on the left adds the rows with first == p and last < r.
+struct LpassArgs {
+    const int64_t *offs; const int32_t *tB, *tS0, *tS0l, *tr; const uint8_t *tb;
+    const int64_t *pos; const int32_t *next; const int64_t *fpos; const int32_t *flast;
+    int32_t *opt, *nnopt, *nlopt, *loc, *loc2, *tileS, *tileS2;
+    int64_t *taskR; const int64_t *tile_t0;
+};
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256, 5) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ a_offs,
+                                               const int32_t *__restrict__ a_tB, const int32_t *__restrict__ a_tS0,
+                                               const int32_t *__restrict__ a_tS0l, const int32_t *__restrict__ a_tr,
+                                               const uint8_t *__restrict__ a_tb, const int64_t *__restrict__ a_pos,
+                                               const int32_t *__restrict__ a_next, const int64_t *__restrict__ a_fpos,
+                                               const int32_t *__restrict__ a_flast, int32_t *__restrict__ a_opt,
+                                               int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
+                                               int32_t *__restrict__ a_loc, int32_t *__restrict__ a_loc2,
+                                               int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2,
+                                               int64_t *__restrict__ a_taskR, const int64_t *__restrict__ a_tile_t0,
+                                               const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR)
+{
+    __shared__ int64_t s_off_all[4][LT + 2];
+    __shared__ unsigned long long s_hd_all[4][LT / 64];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    int64_t tile_start = tile * LT;
+    bool active = tile_start < T;
+    int64_t *s_off = s_off_all[wave];
+    unsigned long long *s_hd = s_hd_all[wave];
+    int64_t t0 = active ? a_tile_t0[tile] : 0; int cnt;
+    load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
+    __syncthreads();
+    if (!active) return;
+    // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
+    int head_at0 = (s_off[0] == tile_start) ? 1 : 0;
+    int hd_before = 0;                                  // heads in the groups already processed
+    int64_t n1 = R.n + 1;
+    int64_t tile_last = tile_start + LT - 1;
+    if (tile_last > T - 1) tile_last = T - 1;
+
+    constexpr int NG = LT / 64;
+    int32_t carryS = 0, carryS2 = 0;                   // segmented-sum state across the groups of the tile
+    Best<TC, HYP> bcarry; best_clear(bcarry);
+    for (int g = 0; g < NG; g++) {
+        int64_t e = tile_start + g * 64 + lane;
+        bool valid = e <= tile_last;
+        int64_t t = 0, i = 0, r = 0, B = 0, p = -1, toff = 0, seg_last = -1, s = 0, en = 0, s2 = 0, en2 = 0, posr = 0;
+        int32_t s0 = 0, s0l = 0; TC wp = (TC)0;
+        unsigned long long hmask = s_hd[g];
+        if (valid) {
+            int li = hd_before + __popcll(hmask & ((2ull << lane) - 1)) - head_at0;
+            t = t0 + li;
+            toff = s_off[li];
+            seg_last = ((li + 1 < cnt) ? s_off[li + 1] : a_offs[t + 1]) - 1;
+            i = e - toff;
+            r = a_tr[t]; B = a_tB[t]; s0 = a_tS0[t];
+            if (HYP) s0l = a_tS0l[t];
+            p = B - i;
+            if (i == 0) { s = en = a_pos[B]; if (HYP) s2 = en2 = a_fpos[B]; }
+            else { s = a_pos[p]; en = a_pos[p + 1]; if (HYP) { s2 = a_fpos[p]; en2 = a_fpos[p + 1]; } }
+            posr = a_pos[r];
+            wp = W[p];
+            if (i == 0 && R.isA) p = -1;              // round A: element 0 (p = r) is not a candidate
+        }
+        hd_before += __popcll(hmask);
+        int32_t thr = valid ? (int32_t)r : INT32_MAX;
+        int32_t d = coop_count<true>(a_next, s, en, thr, valid, lane);                  // next[q] >= r
+        int32_t d2 = 0;
+        if (HYP) d2 = coop_count<false>(a_flast, s2, en2, thr, valid, lane);           // last < r
         // ---- segmented prefix of the step counts (restart at every task head)
         int f = valid ? (i == 0) : 1;
         int32_t x = d;
         wave_segsum(x, f, lane);
         if (!f) x += carryS;
-        int nf = __shfl(f, 63);
-        int32_t nS = __shfl(x, 63);
-        carryS = nS; carryF |= nf;
+        carryS = __shfl(x, 63);
+        int32_t x2 = 0;
+        if (HYP) {
+            int f2 = valid ? (i == 0) : 1;
+            x2 = d2;
+            wave_segsum(x2, f2, lane);
+            if (!f2) x2 += carryS2;
+            carryS2 = __shfl(x2, 63);
+        }
         // ---- evaluate (only where the task head lies in this tile: the count is final)
         bool head_in_tile = valid && toff >= tile_start;
-        Best<TC> bx; bx.p = -1; bx.nn = 0; bx.v = (TC)0;
+        Best<TC, HYP> bx; best_clear(bx);
         if (head_in_tile && p >= 0) {
-            int64_t nn = (int64_t)s0 + x;
-            TC fv = dm_apply(M, alpha, r - p, posr - s, nn, (int64_t)0);     // s == pos[p] for every candidate
-            bx.v = cadd(wp, fv); bx.p = (int32_t)p; bx.nn = (int32_t)nn;
+            int64_t nn = (int64_t)s0 + x, nl = HYP ? (int64_t)s0l + x2 : 0;
+            TC fv = dm_apply(M, alpha, r - p, posr - s, nn, nl);     // s == pos[p] for every candidate
+            bx.v = cadd(wp, fv); bx.p = (int32_t)p; bx.nn = (int32_t)nn; best_set_nl(bx, (int32_t)nl);
         } else if (valid && !head_in_tile) {
-            loc[e] = x;                                 // count since the tile start; finished by k_open
+            a_loc[e] = x;                               // counts since the tile start; finished by k_open
+            if (HYP) a_loc2[e] = x2;
         }
         int bf = valid ? (i == 0) : 1;
-        if (!(dbg & 2)) wave_segmin(bx, bf, lane);
+        wave_segmin<TC, HYP>(bx, bf, lane);
         if (!bf) bx = better(bcarry, bx);
         {
-            Best<TC> nb; nb.v = shfl64(bx.v, 63); nb.p = __shfl(bx.p, 63); nb.nn = __shfl(bx.nn, 63);
+            Best<TC, HYP> nb; best_clear(nb); nb.v = shfl64(bx.v, 63); nb.p = __shfl(bx.p, 63); nb.nn = __shfl(bx.nn, 63);
+            if (HYP) best_set_nl(nb, __shfl(best_nl(bx), 63));
             bcarry = nb;
         }
         if (head_in_tile) {
             if (e == seg_last) {
-                int b = tb[t];
-                opt[(int64_t)b * n1 + r] = bx.p;
-                nnopt[(int64_t)b * n1 + r] = bx.nn;
+                int b = a_tb[t];
+                a_opt[(int64_t)b * n1 + r] = bx.p;
+                a_nnopt[(int64_t)b * n1 + r] = bx.nn;
+                if (HYP) a_nlopt[(int64_t)b * n1 + r] = best_nl(bx);
             } else if (e == tile_last) {
-                partR[tile] = bx; taskR[tile] = t;
+                partR[tile] = bx; a_taskR[tile] = t;
             }
         }
     }
-    if (lane == 0) tileS[tile] = carryS;    // counts since the last head of the tile (or the whole tile)
-    (void)carryF;
+    if (lane == 0) { a_tileS[tile] = carryS; if (HYP) a_tileS2[tile] = carryS2; }   // counts since the last head of the tile
 }
 
 // ------------------------------------------------------------------ open-left part of a tile (task started in an earlier tile)
-template <typename TC>
-__global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ offs,
-                                              const int32_t *__restrict__ tB, const int32_t *__restrict__ tS0,
-                                              const int32_t *__restrict__ tr, const int64_t *__restrict__ pos,
-                                              const int32_t *__restrict__ loc, const int64_t *__restrict__ tilePS,
-                                              const int64_t *__restrict__ tile_t0,
-                                              const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC> *__restrict__ partL)
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
+                                              const int32_t *__restrict__ a_tB, const int32_t *__restrict__ a_tS0,
+                                              const int32_t *__restrict__ a_tS0l, const int32_t *__restrict__ a_tr,
+                                              const int64_t *__restrict__ a_pos, const int32_t *__restrict__ a_loc,
+                                              const int32_t *__restrict__ a_loc2, const int64_t *__restrict__ a_tile_t0,
+                                              const int64_t *__restrict__ tilePS,
+                                              const int64_t *__restrict__ tilePS2, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                              Best<TC, HYP> *__restrict__ partL)
 {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= ntile) return;
     int64_t tile_start = tile * LT;
-    int64_t t = tile_t0[tile];                          // task of the tile's first step
-    int64_t toff = offs[t];
+    int64_t t = a_tile_t0[tile];                        // task of the tile's first step
+    int64_t toff = a_offs[t];
     if (toff >= tile_start) return;                     // tile starts with a head: nothing open on the left
-    int64_t last = offs[t + 1] - 1;
+    int64_t last = a_offs[t + 1] - 1;
     int64_t tile_last = tile_start + LT - 1;
     if (tile_last > T - 1) tile_last = T - 1;
     if (last > tile_last) last = tile_last;
-    int64_t r = tr[t], B = tB[t];
+    int64_t r = a_tr[t], B = a_tB[t];
     // counts of this task in earlier tiles: its head tile contributes "since the last head", every tile in
     // between is covered entirely by the task: a range sum over the per-tile tails (tilePS = their prefix sums)
-    int64_t base = (int64_t)tS0[t] + (tilePS[tile] - tilePS[toff / LT]);
-    Best<TC> best; best.p = -1; best.nn = 0; best.v = (TC)0;
+    int64_t base = (int64_t)a_tS0[t] + (tilePS[tile] - tilePS[toff / LT]);
+    int64_t base2 = HYP ? (int64_t)a_tS0l[t] + (tilePS2[tile] - tilePS2[toff / LT]) : 0;
+    Best<TC, HYP> best; best_clear(best);
     for (int64_t e = tile_start + lane; e <= last; e += 64) {
         int64_t p = B - (e - toff);
-        int64_t nn = base + loc[e];
-        TC fv = dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, (int64_t)0);
-        Best<TC> c; c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn;
+        int64_t nn = base + a_loc[e], nl = HYP ? base2 + a_loc2[e] : 0;
+        TC fv = dm_apply(M, alpha, r - p, a_pos[r] - a_pos[p], nn, nl);
+        Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
         best = better(best, c);                         // a lane visits its steps in increasing e (decreasing p)
     }
     // wave arg-min; ties -> larger p
     for (int o = 32; o > 0; o >>= 1) {
-        Best<TC> c; c.v = shfl64(best.v, (lane + o) & 63); c.p = __shfl(best.p, (lane + o) & 63); c.nn = __shfl(best.nn, (lane + o) & 63);
+        int src = (lane + o) & 63;
+        Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
+        if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
         bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
         if (lane + o < 64 && take) best = c;
     }
@@ -425,20 +480,20 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
 }
 
 // a task whose steps span several tiles: combine the head tile's partial with the partials of the tiles it covers
-template <typename TC>
+template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
-                                             const Best<TC> *__restrict__ partL, const Best<TC> *__restrict__ partR,
+                                             const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
                                              const int32_t *__restrict__ tr, const uint8_t *__restrict__ tb,
-                                             int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int64_t n1)
+                                             int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
 {
     int64_t tile = blockIdx.x;
     int64_t t = taskR[tile];
     if (t < 0) return;
-    __shared__ Best<TC> s_B[256];
+    __shared__ Best<TC, HYP> s_B[256];
     int64_t end_tile = (offs[t + 1] - 1) / LT;
-    Best<TC> acc; acc.p = -1; acc.nn = 0; acc.v = (TC)0;
+    Best<TC, HYP> acc; best_clear(acc);
     for (int64_t k = tile + 1 + threadIdx.x; k <= end_tile; k += 256) {
-        Best<TC> c = partL[k];
+        Best<TC, HYP> c = partL[k];
         bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
         if (take) acc = c;
     }
@@ -446,17 +501,18 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < (unsigned)o) {
-            Best<TC> a = s_B[threadIdx.x], b = s_B[threadIdx.x + o];
-            bool takeb = (a.p < 0) ? (b.p >= 0) : (b.p >= 0 && (b.v < a.v || (b.v == a.v && b.p > a.p)));
-            if (takeb) s_B[threadIdx.x] = b;
+            Best<TC, HYP> x = s_B[threadIdx.x], y = s_B[threadIdx.x + o];
+            bool takey = (x.p < 0) ? (y.p >= 0) : (y.p >= 0 && (y.v < x.v || (y.v == x.v && y.p > x.p)));
+            if (takey) s_B[threadIdx.x] = y;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        Best<TC> res = better(partR[tile], s_B[0]);     // the head tile holds the larger p: wins ties
+        Best<TC, HYP> res = better(partR[tile], s_B[0]);     // the head tile holds the larger p: wins ties
         int64_t r = tr[t]; int b = tb[t];
         opt[(int64_t)b * n1 + r] = res.p;
         nnopt[(int64_t)b * n1 + r] = res.nn;
+        if (HYP) nlopt[(int64_t)b * n1 + r] = best_nl(res);
     }
 }
 
@@ -464,6 +520,7 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
 template <typename TC>
 __global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int64_t *__restrict__ pos,
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
+                                                 const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  TC *__restrict__ cst, int32_t *__restrict__ ptr)
 {
@@ -476,7 +533,8 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int
         if (!((r >> b) & 1)) continue;
         int64_t p = opt[(int64_t)b * n1 + r];
         int64_t nn = nnopt[(int64_t)b * n1 + r];
-        TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, (int64_t)0));
+        int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + r] : 0;
+        TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, nl));
         if (v < bv) { bv = v; bp = p; }            // lower bits hold larger p: strict < keeps the largest p on ties
     }
     cst[r] = bv;
@@ -486,11 +544,12 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int
 // ------------------------------------------------------------------ host driver for one layer
 template <typename TC>
 struct LayerWork {
-    int64_t n = -1; int nbits = 0;
+    int64_t n = -1; int nbits = 0; bool hyp = false;
     DBuf<int32_t> opt, nnopt, cr, tB, tS0, tr, len, loc, tileS;
+    DBuf<int32_t> nlopt, crl, tS0l, loc2, tileS2;        // hyperedge-cut: second (self-net) count
     DBuf<uint8_t> tb;
-    DBuf<int64_t> offs, scratch, taskR, tilePS, tile_t0;
-    DBuf<Best<TC>> partL, partR;
+    DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
+    DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
     int64_t max_tasks = 0;
 };
 
@@ -515,56 +574,69 @@ static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n)
     R.ntask = acc;
 }
 
+// right part of one round for one counter: rows with ctz == tau stream their 2^tau columns once for all bit planes
+static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n, const int64_t *cpos, const int32_t *link, int ge,
+                         const int32_t *opt, int32_t *cr)
+{
+    int tau = R.tau;
+    int64_t nrows = ((n >> tau) + 1) >> 1;                     // rows (2u+1)<<tau <= n
+    if (tau <= 3) {
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, cpos, link, opt, cr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, cpos, link, opt, cr);
+    } else {
+        int ch_cols = 256;
+        int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
+        if (cpr == 1) ch_cols = 1 << tau;
+        int64_t waves = nrows * cpr;
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
+    }
+}
+
 template <typename TC>
 void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_)
 {
     auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
     hipStream_t s = A->stream;
     int64_t n = A->n;
+    bool hyp = M.kind == CP_MODEL_HYPEREDGE_CUT;
     int nbits = 1;
     while (((int64_t)1 << nbits) <= n) nbits++;
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
-    if (Wk.n != n) {
-        Wk.n = n; Wk.nbits = nbits;
+    if (Wk.n != n || Wk.hyp != hyp) {
+        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp;
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
+        if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
         int64_t mx = n;
         for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n); if (R.ntask > mx) mx = R.ntask; }
         Wk.max_tasks = mx > 0 ? mx : 1;
         size_t mt = (size_t)Wk.max_tasks;
         Wk.tB.alloc(mt); Wk.tS0.alloc(mt); Wk.tr.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
+        if (hyp) Wk.tS0l.alloc(mt);
     }
     double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
+    double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n);
         else make_round(R, false, nbits - rd, nbits, n);
         if (R.ntask <= 0) continue;
         if (!R.isA) {
-            // right part: every row with ctz == tau streams its 2^tau columns once for all of its bit planes
-            int tau = R.tau;
-            int64_t nrows = ((n >> tau) + 1) >> 1;                     // rows (2u+1)<<tau <= n
-            int64_t cols = nrows << tau;
-            ProfScope ps(PROF_RPASS, s, 4.0 * avg_deg * (double)cols + 8.0 * (double)R.ntask);
-            if (tau <= 3) {
-                hipLaunchKernelGGL(k_rpass_small, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, A->pos.p,
-                                   A->prev.p, Wk.opt.p, Wk.cr.p);
-            } else {
-                int ch_cols = 256;
-                int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
-                if (cpr == 1) ch_cols = 1 << tau;
-                if (cpr > 1)
-                    hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
-                                       Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p);
-                int64_t waves = nrows * cpr;
-                hipLaunchKernelGGL(k_rpass_wave, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols,
-                                   A->pos.p, A->prev.p, Wk.opt.p, Wk.cr.p);
-            }
+            int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
+            ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
+            if (((int64_t)1 << R.tau) > 256)          // several chunks per row accumulate with atomics: clear first
+                hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
+                                   Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
+                                   (int32_t *)nullptr);
+            launch_rpass(s, R, nbits, n, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
+            if (hyp) launch_rpass(s, R, nbits, n, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
         {
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
             hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 0,
-                               Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p);
+                               Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr,
+                               hyp ? Wk.crl.p : (int32_t *)nullptr, hyp ? Wk.tS0l.p : (int32_t *)nullptr);
         }
         {
             ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
@@ -577,41 +649,57 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld T=%lld\n", R.isA, R.tau, (long long)R.ntask, (long long)T);
         int64_t ntile = cdiv(T, LT);
         Wk.loc.ensure((size_t)T);
+        if (hyp) Wk.loc2.ensure((size_t)T);
         if (Wk.tileS.n < (size_t)ntile) {
             Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
             Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
+            if (hyp) { Wk.tileS2.alloc((size_t)ntile); Wk.tilePS2.alloc((size_t)ntile + 1); }
         }
+        if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, Wk.tile_t0.p);
+        LpassArgs a;
+        a.offs = Wk.offs.p; a.tB = Wk.tB.p; a.tS0 = Wk.tS0.p; a.tS0l = Wk.tS0l.p; a.tr = Wk.tr.p; a.tb = Wk.tb.p;
+        a.pos = A->pos.p; a.next = A->next.p; a.fpos = hyp ? A->fpos.p : nullptr; a.flast = hyp ? A->flast.p : nullptr;
+        a.opt = Wk.opt.p; a.nnopt = Wk.nnopt.p; a.nlopt = Wk.nlopt.p; a.loc = Wk.loc.p; a.loc2 = Wk.loc2.p;
+        a.tileS = Wk.tileS.p; a.tileS2 = Wk.tileS2.p; a.taskR = Wk.taskR.p; a.tile_t0 = Wk.tile_t0.p;
         {
             // algorithmic bytes of one launch: per flattened step the stepped column's link
-            // entries (4 B x N/n), its colptr entry (8 B), the candidate's previous-layer cost (8 B) and the task
-            // descriptor share (offsets/B/anchor/row, amortised 8 B)
-            ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * avg_deg + 24.0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, R, T, Wk.offs.p, Wk.tB.p,
-                               Wk.tS0.p, Wk.tr.p, Wk.tb.p, A->pos.p, A->next.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.loc.p,
-                               Wk.tileS.p, Wk.partR.p, Wk.taskR.p, Wk.tile_t0.p, (int)g_opt_dbg);
+            // entries (4 B x N/n, plus 4 B x nonempty-rows/n for hyperedge costs), its colptr entry (8 B), the
+            // candidate's previous-layer cost (8 B) and the task-descriptor share (offsets/B/anchor/row, amortised 8 B)
+            ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * (avg_deg + self_deg) + 24.0));
+#define LP_ARGS R, T, a.offs, a.tB, a.tS0, a.tS0l, a.tr, a.tb, a.pos, a.next, a.fpos, a.flast, a.opt, a.nnopt, a.nlopt, a.loc, a.loc2, \
+                a.tileS, a.tileS2, a.taskR, a.tile_t0, W, M, alpha
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, reinterpret_cast<Best<TC, false> *>(Wk.partR.p));
+#undef LP_ARGS
         }
         {
             ProfScope ps(PROF_CARRY, s, 12.0 * (double)ntile);
             exclusive_scan_i32(Wk.tileS.p, Wk.tilePS.p, ntile, Wk.scratch, s);
+            if (hyp) exclusive_scan_i32(Wk.tileS2.p, Wk.tilePS2.p, ntile, Wk.scratch, s);
         }
         {
             ProfScope ps(PROF_EVAL, s, 0.0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, R, T, ntile, Wk.offs.p,
-                               Wk.tB.p, Wk.tS0.p, Wk.tr.p, A->pos.p, Wk.loc.p, Wk.tilePS.p, Wk.tile_t0.p, W, M, alpha, Wk.partL.p);
+#define OP_ARGS R, T, ntile, a.offs, a.tB, a.tS0, a.tS0l, a.tr, a.pos, a.loc, a.loc2, a.tile_t0, Wk.tilePS.p
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, Wk.tilePS2.p, W, M, alpha, Wk.partL.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, (const int64_t *)nullptr, W, M, alpha, reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
+#undef OP_ARGS
         }
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
-                               Wk.partL.p, Wk.partR.p, Wk.tr.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, n + 1);
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+                               Wk.partL.p, Wk.partR.p, Wk.tr.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+                               reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
+                               Wk.tr.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
         }
         CP_HIP(hipGetLastError());
     }
     {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, nbits, A->pos.p,
-                           Wk.opt.p, Wk.nnopt.p, W, M, alpha, cst_out, ptr_out);
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
     CP_HIP(hipGetLastError());
 }

@@ -26,31 +26,55 @@ def link_arrays(A):
     return prev, nxt
 
 
-def layer_total(A, Wprev, fcost, prev, nxt):
-    """Return (cst[r], ptr[r]) for r in 0..n:  min over p<=r of Wprev[p] + fcost(p, r, nets(p,r)),
-    ties -> largest p.  fcost(p, r, nn) is the model applied to (r-p, pins, nn)."""
+def first_last(A):
+    """first / last column (0-based) of every row; -1 for empty rows."""
+    n = A.n
+    first = np.full(A.m, -1, dtype=np.int64); last = np.full(A.m, -1, dtype=np.int64)
+    cols = np.repeat(np.arange(n), np.diff(A.colptr))
+    for q in range(A.nnz):
+        i = A.rowval[q] - 1
+        if first[i] < 0:
+            first[i] = cols[q]
+        last[i] = cols[q]
+    return first, last
+
+
+def layer_total(A, Wprev, fcost, prev, nxt, first=None, last=None):
+    """Return (cst[r], ptr[r]) for r in 0..n:  min over p<=r of Wprev[p] + fcost(p, r, nets(p,r)[, selfnets(p,r)]),
+    ties -> largest p.  With first/last given the count is the pair (nets, selfnets) (hyperedge-cut costs):
+    selfnets(p, r) = #rows with first >= p and last < r; a column c joining on the right of a part starting at B
+    adds the rows with last == c and first >= B; a column p joining on the left of a part ending before r adds
+    the rows with first == p and last < r."""
     n = A.n
     pos = A.colptr - 1
     nb = max(1, int(n).bit_length())
     opt = np.full((n + 1, nb), -1, dtype=np.int64)
-    nnopt = np.zeros((n + 1, nb), dtype=np.int64)
+    nnopt = np.zeros((n + 1, nb), dtype=object)
     val = np.full((n + 1, nb), np.inf)
+    hyper = first is not None
+    zero = np.array([0, 0]) if hyper else 0
 
     def right_delta(c, thr):      # add column c on the right of a part starting at thr
-        return int(np.sum(prev[pos[c]:pos[c + 1]] < thr))
+        d = int(np.sum(prev[pos[c]:pos[c + 1]] < thr))
+        if hyper:
+            return np.array([d, int(np.sum((last == c) & (first >= thr)))])
+        return d
 
     def left_delta(p, r):         # add column p on the left of a part ending before r
-        return int(np.sum(nxt[pos[p]:pos[p + 1]] >= r))
+        d = int(np.sum(nxt[pos[p]:pos[p + 1]] >= r))
+        if hyper:
+            return np.array([d, int(np.sum((first == p) & (last < r)))])
+        return d
 
     def run_task(r, b, B, a, S0, cols_right, virtual):
-        nn = S0
+        nn = S0 + 0                # copy: the hyperedge count is a numpy pair
         best = None
         for c in cols_right:
-            nn += right_delta(c, B)
+            nn = nn + right_delta(c, B)
         if not virtual:
             best = (Wprev[B] + fcost(B, r, nn), B, nn)
         for p in range(B - 1, a - 1, -1):
-            nn += left_delta(p, r)
+            nn = nn + left_delta(p, r)
             v = Wprev[p] + fcost(p, r, nn)
             if best is None or v < best[0]:        # strict: ties keep the larger p
                 best = (v, p, nn)
@@ -59,7 +83,7 @@ def layer_total(A, Wprev, fcost, prev, nxt):
     # round A: rho == 0 rows of every rectangle
     for r in range(1, n + 1):
         b = (r & -r).bit_length() - 1
-        run_task(r, b, r, r - (1 << b), 0, [], True)
+        run_task(r, b, r, r - (1 << b), zero, [], True)
     # rounds tau = high .. 0
     for tau in range(nb - 1, -1, -1):
         for r in range(1 << tau, n + 1, 1 << (tau + 1)):      # ctz(r) == tau
@@ -77,7 +101,7 @@ def layer_total(A, Wprev, fcost, prev, nxt):
     cst = np.zeros(n + 1, dtype=object)
     ptr = np.zeros(n + 1, dtype=np.int64)
     for r in range(n + 1):
-        bv, bp = Wprev[r] + fcost(r, r, 0), r
+        bv, bp = Wprev[r] + fcost(r, r, zero), r
         for b in range(nb):
             if (r >> b) & 1 and val[r, b] < bv:
                 bv, bp = val[r, b], opt[r, b]

@@ -20,7 +20,12 @@ def mats():
 
 MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100),
           cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0), cp.AffineConnectivityModel(2, -3, 1, 3),
-          cp.AffineWorkModel(0, 10, 1)]
+          cp.AffineWorkModel(0, 10, 1),
+          # hyperedge-cut costs in the inverse-Monge class (b_cut >= 0, b_self <= b_cut): fast scheme with two counts
+          cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3),
+          cp.AffineHyperedgeCutModel(0.0, 0.0, 0.0, -1.0, 0.0),
+          # outside the class (b_self > b_cut): must take the general sweep and still match
+          cp.AffineHyperedgeCutModel(0, 0, 0, 1, 0)]
 
 
 def test_link_array_matches_reference_sweep(hip, orc):
@@ -49,7 +54,8 @@ def test_total_splitter_tables_bit_exact(hip, orc, mi):
 def test_fast_path_equals_general_sweep(hip, orc):
     """The O(n log^2 n) scheme and the literal O(n^2) device sweep agree with the oracle on a mid-size input."""
     A = suitesparse_shaped(3000, 8, 11)
-    for mdl in (cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+    for mdl in (cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100),
+                cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), cp.AffineHyperedgeCutModel(0, 10, 1, 30, 100)):
         K = 6
         want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=orc)
         fast = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)
