@@ -170,6 +170,12 @@ __global__ void k_fill_col(const int64_t *__restrict__ pos, int32_t *__restrict_
     col[q] = (int32_t)lo;
 }
 
+__global__ void k_narrow(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
 __global__ void k_iota(uint32_t *__restrict__ v, int64_t N)
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,6 +223,8 @@ void ensure_links(cp_csr_s *A)
     A->col.alloc(Na); A->prev.alloc(Na + 8); A->next.alloc(Na + 8);     // +8: 16-byte vector loads may over-read the tail
     A->rfirst.alloc((size_t)(m > 0 ? m : 1)); A->rlast.alloc((size_t)(m > 0 ? m : 1));
     A->tpos.alloc((size_t)m + 1); A->tq.alloc(Na);
+    A->pos32.alloc((size_t)n + 1);
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->pos.p, A->pos32.p, n + 1);
     CP_HIP(hipMemsetAsync(A->rfirst.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
     CP_HIP(hipMemsetAsync(A->rlast.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
     CP_HIP(hipMemsetAsync(A->tpos.p, 0, sizeof(int64_t) * ((size_t)m + 1), s));
@@ -286,6 +294,9 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,
                                   A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, m);
+    A->fpos32.alloc((size_t)n + 1); A->lpos32.alloc((size_t)n + 1);
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->fpos.p, A->fpos32.p, n + 1);
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->lpos.p, A->lpos32.p, n + 1);
     CP_HIP(hipGetLastError());
     CP_HIP(hipStreamSynchronize(s));
     A->have_self = true;
@@ -295,6 +306,7 @@ void drop_cache(cp_csr_s *A)
 {
     A->have_links = false; A->have_self = false;
     A->col.release(); A->prev.release(); A->next.release(); A->rfirst.release(); A->rlast.release();
+    A->pos32.release(); A->fpos32.release(); A->lpos32.release();
     A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release();
 }
 

@@ -16,6 +16,7 @@ struct cp_csr_s {
     cpk::DBuf<int32_t> next;    // N : next column holding the same row, n if none
     cpk::DBuf<int32_t> rfirst;  // m : first column of each row (-1 if the row is empty)
     cpk::DBuf<int32_t> rlast;   // m : last column
+    cpk::DBuf<int32_t> pos32;   // n+1 : pos narrowed to 32 bits (N < 2^31) for the DP kernels
     cpk::DBuf<int64_t> tpos;    // m+1 : start of each row in the row-major order (transpose pointer)
     cpk::DBuf<int32_t> tq;      // N : nonzero ids sorted by (row, column)
     // rows bucketed by first column (self-net left steps) and by last column (right steps)
@@ -23,6 +24,7 @@ struct cp_csr_s {
     cpk::DBuf<int64_t> fpos;    // n+1
     cpk::DBuf<int32_t> flast;   // #nonempty rows : last column of rows whose first column is c
     cpk::DBuf<int64_t> lpos;    // n+1
+    cpk::DBuf<int32_t> fpos32, lpos32;   // 32-bit copies
     cpk::DBuf<int32_t> lfirst;  // #nonempty rows : first column of rows whose last column is c
     int64_t nrows_nonempty = 0;
 };

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
 // left steps p = B - i.  Round A: B = r is virtual (not a candidate), anchor 0.
 __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                int32_t *__restrict__ cr, int zero_cr_only,
-                                               int32_t *__restrict__ tB, int32_t *__restrict__ tS0, int32_t *__restrict__ tr,
+                                               int4 *__restrict__ tdesc, const int32_t *__restrict__ pos32,
                                                uint8_t *__restrict__ tb, int32_t *__restrict__ len,
                                                const int32_t *__restrict__ nlopt, int32_t *__restrict__ crl, int32_t *__restrict__ tS0l)
 {
@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__res
         a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
         if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
     }
-    tB[t] = (int32_t)B; tS0[t] = (int32_t)S0; tr[t] = (int32_t)r; tb[t] = (uint8_t)b;
+    tdesc[t] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);      // one 16-byte record per task
+    tb[t] = (uint8_t)b;
     len[t] = (int32_t)(1 + (B - a));
     if (tS0l) tS0l[t] = (int32_t)S0l;
 }
@@ -230,17 +231,19 @@ __global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ off
     tile_t0[tile] = lo;
 }
 
-// loads the offsets of the tasks overlapping the tile and a bitmap of the task heads inside it
+// loads the offsets (relative to the tile start, 32-bit) of the tasks overlapping the tile and a bitmap of the
+// task heads inside it
 __device__ __forceinline__ void load_tile_tasks(const int64_t *__restrict__ offs, int64_t ntask, int64_t t0, int64_t tile_start,
-                                                bool active, int64_t *s_off, unsigned long long *s_hd, int lane, int &cnt)
+                                                bool active, int32_t *s_off, unsigned long long *s_hd, int lane, int &cnt)
 {
     int64_t c = ntask - t0;                  // every task has len >= 1: at most LT tasks start inside the tile
     cnt = active ? (int)(c > LT + 1 ? LT + 1 : c) : 0;
     if (lane < LT / 64) s_hd[lane] = 0ull;
     for (int i = lane; i < cnt; i += 64) {
-        int64_t o = offs[t0 + i];
-        s_off[i] = o;
-        int64_t rel = o - tile_start;
+        int64_t rel = offs[t0 + i] - tile_start;
+        if (rel < -(int64_t)0x3fffffff) rel = -(int64_t)0x3fffffff;
+        if (rel > (int64_t)0x3fffffff) rel = (int64_t)0x3fffffff;
+        s_off[i] = (int32_t)rel;
         if (rel >= 0 && rel < LT) atomicOr(&s_hd[rel >> 6], 1ull << (rel & 63));
     }
 }
@@ -252,9 +255,9 @@ __device__ __forceinline__ void load_tile_tasks(const int64_t *__restrict__ offs
 // #{entries of its range with  v >= thr (GE)  or  v < thr (!GE)}.  One ballot pass per distinct threshold
 // (= task) touching a 256-entry block.
 template <bool GE>
-__device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, int64_t s, int64_t en, int32_t thr, bool valid, int lane)
+__device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, int32_t s, int32_t en, int32_t thr, bool valid, int lane)
 {
-    int64_t prev_s = shfl_up64(s, 1);
+    int32_t prev_s = __shfl_up(s, 1);
     int prev_valid = __shfl_up((int)valid, 1);
     bool cont = valid && lane > 0 && prev_valid && (en == prev_s);
     unsigned long long heads = __ballot(valid && !cont);
@@ -267,24 +270,24 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
         int h1 = heads ? (__ffsll((long long)heads) - 1) : 64;
         unsigned long long inrun = vm & (h1 == 64 ? ~0ull : ((1ull << h1) - 1)) & ~((1ull << h0) - 1);
         int hl = 63 - __clzll((long long)inrun);          // last valid lane of the run
-        int64_t q_hi = shfl64(en, h0), q_lo = shfl64(s, hl);
+        int32_t q_hi = __shfl(en, h0), q_lo = __shfl(s, hl);
         bool mine = lane >= h0 && lane <= hl && en > s;
-        for (int64_t x = q_lo & ~(int64_t)3; x < q_hi; x += 512) {
+        for (int32_t x = q_lo & ~3; x < q_hi; x += 512) {
             int4 v0 = make_int4(FILL, FILL, FILL, FILL), v1 = v0;
-            int64_t b0 = x + 4 * lane, b1 = b0 + 256;
+            int32_t b0 = x + 4 * lane, b1 = b0 + 256;
             if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(arr + b0);        // arrays are padded by 8 entries
             if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(arr + b1);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                int64_t xc = x + c * 256;
+                int32_t xc = x + c * 256;
                 if (xc >= q_hi) break;                    // wave-uniform
                 int4 v = c ? v1 : v0;
-                int64_t pb = xc + 4 * lane;               // position of component 0
+                int32_t pb = xc + 4 * lane;               // position of component 0
                 bool in0 = pb >= q_lo && pb < q_hi, in1 = pb + 1 >= q_lo && pb + 1 < q_hi;
                 bool in2 = pb + 2 >= q_lo && pb + 2 < q_hi, in3 = pb + 3 >= q_lo && pb + 3 < q_hi;
                 bool ov = mine && s < xc + 256 && en > xc;
                 // this lane's range covers positions [a0, a1) of the block: lanes [lo_j, hi_j) of component j
-                int a0 = ov ? (int)((s > xc ? s : xc) - xc) : 0, a1 = ov ? (int)((en < xc + 256 ? en : xc + 256) - xc) : 0;
+                int a0 = ov ? ((s > xc ? s : xc) - xc) : 0, a1 = ov ? ((en < xc + 256 ? en : xc + 256) - xc) : 0;
                 unsigned long long rem = __ballot(ov);
                 while (rem) {                             // one pass per distinct threshold touching the block
                     int l = __ffsll((long long)rem) - 1;
@@ -318,71 +321,65 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
 // HYP: hyperedge-cut costs carry a second count (self nets): rows bucketed by their FIRST column (fpos / flast),
 // a column p joining on the left adds the rows with first == p and last < r.
-struct LpassArgs {
-    const int64_t *offs; const int32_t *tB, *tS0, *tS0l, *tr; const uint8_t *tb;
-    const int64_t *pos; const int32_t *next; const int64_t *fpos; const int32_t *flast;
-    int32_t *opt, *nnopt, *nlopt, *loc, *loc2, *tileS, *tileS2;
-    int64_t *taskR; const int64_t *tile_t0;
-};
 
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256, 5) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ a_offs,
-                                               const int32_t *__restrict__ a_tB, const int32_t *__restrict__ a_tS0,
-                                               const int32_t *__restrict__ a_tS0l, const int32_t *__restrict__ a_tr,
-                                               const uint8_t *__restrict__ a_tb, const int64_t *__restrict__ a_pos,
-                                               const int32_t *__restrict__ a_next, const int64_t *__restrict__ a_fpos,
-                                               const int32_t *__restrict__ a_flast, int32_t *__restrict__ a_opt,
-                                               int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
-                                               int32_t *__restrict__ a_loc, int32_t *__restrict__ a_loc2,
-                                               int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2,
-                                               int64_t *__restrict__ a_taskR, const int64_t *__restrict__ a_tile_t0,
-                                               const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR)
+__global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ a_offs,
+                                                  const int4 *__restrict__ a_tdesc, const int32_t *__restrict__ a_tS0l,
+                                                  const uint8_t *__restrict__ a_tb, const int32_t *__restrict__ a_pos,
+                                                  const int32_t *__restrict__ a_next, const int32_t *__restrict__ a_fpos,
+                                                  const int32_t *__restrict__ a_flast, int32_t *__restrict__ a_opt,
+                                                  int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
+                                                  int32_t *__restrict__ a_loc, int32_t *__restrict__ a_loc2,
+                                                  int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2,
+                                                  int64_t *__restrict__ a_taskR, const int64_t *__restrict__ a_tile_t0,
+                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR)
 {
-    __shared__ int64_t s_off_all[4][LT + 2];
+    __shared__ int32_t s_off_all[4][LT + 2];
     __shared__ unsigned long long s_hd_all[4][LT / 64];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     int64_t tile_start = tile * LT;
     bool active = tile_start < T;
-    int64_t *s_off = s_off_all[wave];
+    int32_t *s_off = s_off_all[wave];
     unsigned long long *s_hd = s_hd_all[wave];
     int64_t t0 = active ? a_tile_t0[tile] : 0; int cnt;
     load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     __syncthreads();
     if (!active) return;
     // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
-    int head_at0 = (s_off[0] == tile_start) ? 1 : 0;
+    int head_at0 = (s_off[0] == 0) ? 1 : 0;
     int hd_before = 0;                                  // heads in the groups already processed
     int64_t n1 = R.n + 1;
-    int64_t tile_last = tile_start + LT - 1;
-    if (tile_last > T - 1) tile_last = T - 1;
+    int32_t tile_last = (T - tile_start < LT) ? (int32_t)(T - tile_start) - 1 : LT - 1;     // relative to the tile start
+    // everything below is 32-bit: step indices are relative to the tile, nonzero positions are < 2^31
 
     constexpr int NG = LT / 64;
     int32_t carryS = 0, carryS2 = 0;                   // segmented-sum state across the groups of the tile
     Best<TC, HYP> bcarry; best_clear(bcarry);
     for (int g = 0; g < NG; g++) {
-        int64_t e = tile_start + g * 64 + lane;
+        int32_t e = g * 64 + lane;
         bool valid = e <= tile_last;
-        int64_t t = 0, i = 0, r = 0, B = 0, p = -1, toff = 0, seg_last = -1, s = 0, en = 0, s2 = 0, en2 = 0, posr = 0;
+        int32_t t = 0, i = 0, r = 0, B = 0, p = -1, toff = 0, seg_last = -1, s = 0, en = 0, s2 = 0, en2 = 0, posr = 0;
         int32_t s0 = 0, s0l = 0; TC wp = (TC)0;
         unsigned long long hmask = s_hd[g];
         if (valid) {
             int li = hd_before + __popcll(hmask & ((2ull << lane) - 1)) - head_at0;
-            t = t0 + li;
+            t = (int32_t)t0 + li;
             toff = s_off[li];
-            seg_last = ((li + 1 < cnt) ? s_off[li + 1] : a_offs[t + 1]) - 1;
+            if (li + 1 < cnt) seg_last = s_off[li + 1] - 1;
+            else { int64_t nx = a_offs[(int64_t)t + 1] - tile_start; seg_last = nx > 0x3fffffff ? 0x3fffffff : (int32_t)nx - 1; }
             i = e - toff;
-            r = a_tr[t]; B = a_tB[t]; s0 = a_tS0[t];
+            int4 td = a_tdesc[t];
+            B = td.x; s0 = td.y; r = td.z; posr = td.w;
             if (HYP) s0l = a_tS0l[t];
             p = B - i;
             if (i == 0) { s = en = a_pos[B]; if (HYP) s2 = en2 = a_fpos[B]; }
             else { s = a_pos[p]; en = a_pos[p + 1]; if (HYP) { s2 = a_fpos[p]; en2 = a_fpos[p + 1]; } }
-            posr = a_pos[r];
             wp = W[p];
             if (i == 0 && R.isA) p = -1;              // round A: element 0 (p = r) is not a candidate
         }
         hd_before += __popcll(hmask);
-        int32_t thr = valid ? (int32_t)r : INT32_MAX;
+        int32_t thr = valid ? r : INT32_MAX;
         int32_t d = coop_count<true>(a_next, s, en, thr, valid, lane);                  // next[q] >= r
         int32_t d2 = 0;
         if (HYP) d2 = coop_count<false>(a_flast, s2, en2, thr, valid, lane);           // last < r
@@ -401,15 +398,15 @@ __global__ void __launch_bounds__(256, 5) k_lpass(RoundDesc R, int64_t T, const 
             carryS2 = __shfl(x2, 63);
         }
         // ---- evaluate (only where the task head lies in this tile: the count is final)
-        bool head_in_tile = valid && toff >= tile_start;
+        bool head_in_tile = valid && toff >= 0;
         Best<TC, HYP> bx; best_clear(bx);
         if (head_in_tile && p >= 0) {
             int64_t nn = (int64_t)s0 + x, nl = HYP ? (int64_t)s0l + x2 : 0;
-            TC fv = dm_apply(M, alpha, r - p, posr - s, nn, nl);     // s == pos[p] for every candidate
-            bx.v = cadd(wp, fv); bx.p = (int32_t)p; bx.nn = (int32_t)nn; best_set_nl(bx, (int32_t)nl);
+            TC fv = dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - s), nn, nl);     // s == pos[p] for every candidate
+            bx.v = cadd(wp, fv); bx.p = p; bx.nn = (int32_t)nn; best_set_nl(bx, (int32_t)nl);
         } else if (valid && !head_in_tile) {
-            a_loc[e] = x;                               // counts since the tile start; finished by k_open
-            if (HYP) a_loc2[e] = x2;
+            a_loc[tile_start + e] = x;                  // counts since the tile start; finished by k_open
+            if (HYP) a_loc2[tile_start + e] = x2;
         }
         int bf = valid ? (i == 0) : 1;
         wave_segmin<TC, HYP>(bx, bf, lane);
@@ -426,7 +423,7 @@ __global__ void __launch_bounds__(256, 5) k_lpass(RoundDesc R, int64_t T, const 
                 a_nnopt[(int64_t)b * n1 + r] = bx.nn;
                 if (HYP) a_nlopt[(int64_t)b * n1 + r] = best_nl(bx);
             } else if (e == tile_last) {
-                partR[tile] = bx; a_taskR[tile] = t;
+                partR[tile] = bx; a_taskR[tile] = (int64_t)t;
             }
         }
     }
@@ -436,9 +433,9 @@ __global__ void __launch_bounds__(256, 5) k_lpass(RoundDesc R, int64_t T, const 
 // ------------------------------------------------------------------ open-left part of a tile (task started in an earlier tile)
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
-                                              const int32_t *__restrict__ a_tB, const int32_t *__restrict__ a_tS0,
-                                              const int32_t *__restrict__ a_tS0l, const int32_t *__restrict__ a_tr,
-                                              const int64_t *__restrict__ a_pos, const int32_t *__restrict__ a_loc,
+                                              const int4 *__restrict__ a_tdesc,
+                                              const int32_t *__restrict__ a_tS0l,
+                                              const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_loc,
                                               const int32_t *__restrict__ a_loc2, const int64_t *__restrict__ a_tile_t0,
                                               const int64_t *__restrict__ tilePS,
                                               const int64_t *__restrict__ tilePS2, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
@@ -455,16 +452,17 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
     int64_t tile_last = tile_start + LT - 1;
     if (tile_last > T - 1) tile_last = T - 1;
     if (last > tile_last) last = tile_last;
-    int64_t r = a_tr[t], B = a_tB[t];
+    int4 td = a_tdesc[t];
+    int64_t r = td.z, B = td.x;
     // counts of this task in earlier tiles: its head tile contributes "since the last head", every tile in
     // between is covered entirely by the task: a range sum over the per-tile tails (tilePS = their prefix sums)
-    int64_t base = (int64_t)a_tS0[t] + (tilePS[tile] - tilePS[toff / LT]);
+    int64_t base = (int64_t)td.y + (tilePS[tile] - tilePS[toff / LT]);
     int64_t base2 = HYP ? (int64_t)a_tS0l[t] + (tilePS2[tile] - tilePS2[toff / LT]) : 0;
     Best<TC, HYP> best; best_clear(best);
     for (int64_t e = tile_start + lane; e <= last; e += 64) {
         int64_t p = B - (e - toff);
         int64_t nn = base + a_loc[e], nl = HYP ? base2 + a_loc2[e] : 0;
-        TC fv = dm_apply(M, alpha, r - p, a_pos[r] - a_pos[p], nn, nl);
+        TC fv = dm_apply(M, alpha, r - p, (int64_t)(td.w - a_pos[p]), nn, nl);
         Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
         best = better(best, c);                         // a lane visits its steps in increasing e (decreasing p)
     }
@@ -483,7 +481,7 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
                                              const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
-                                             const int32_t *__restrict__ tr, const uint8_t *__restrict__ tb,
+                                             const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
                                              int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
 {
     int64_t tile = blockIdx.x;
@@ -509,7 +507,7 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
     }
     if (threadIdx.x == 0) {
         Best<TC, HYP> res = better(partR[tile], s_B[0]);     // the head tile holds the larger p: wins ties
-        int64_t r = tr[t]; int b = tb[t];
+        int64_t r = tdesc[t].z; int b = tb[t];
         opt[(int64_t)b * n1 + r] = res.p;
         nnopt[(int64_t)b * n1 + r] = res.nn;
         if (HYP) nlopt[(int64_t)b * n1 + r] = best_nl(res);
@@ -545,7 +543,8 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int
 template <typename TC>
 struct LayerWork {
     int64_t n = -1; int nbits = 0; bool hyp = false;
-    DBuf<int32_t> opt, nnopt, cr, tB, tS0, tr, len, loc, tileS;
+    DBuf<int32_t> opt, nnopt, cr, len, loc, tileS;
+    DBuf<int4> tdesc;                                    // per task {B, anchor count, row r, pos32[r]}
     DBuf<int32_t> nlopt, crl, tS0l, loc2, tileS2;        // hyperedge-cut: second (self-net) count
     DBuf<uint8_t> tb;
     DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
@@ -612,7 +611,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n); if (R.ntask > mx) mx = R.ntask; }
         Wk.max_tasks = mx > 0 ? mx : 1;
         size_t mt = (size_t)Wk.max_tasks;
-        Wk.tB.alloc(mt); Wk.tS0.alloc(mt); Wk.tr.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
+        Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
         if (hyp) Wk.tS0l.alloc(mt);
     }
     double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
@@ -627,7 +626,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
             if (((int64_t)1 << R.tau) > 256)          // several chunks per row accumulate with atomics: clear first
                 hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
-                                   Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
+                                   Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
                                    (int32_t *)nullptr);
             launch_rpass(s, R, nbits, n, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
             if (hyp) launch_rpass(s, R, nbits, n, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
@@ -635,7 +634,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         {
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
             hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 0,
-                               Wk.tB.p, Wk.tS0.p, Wk.tr.p, Wk.tb.p, Wk.len.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr,
+                               Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr,
                                hyp ? Wk.crl.p : (int32_t *)nullptr, hyp ? Wk.tS0l.p : (int32_t *)nullptr);
         }
         {
@@ -658,18 +657,14 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, Wk.tile_t0.p);
-        LpassArgs a;
-        a.offs = Wk.offs.p; a.tB = Wk.tB.p; a.tS0 = Wk.tS0.p; a.tS0l = Wk.tS0l.p; a.tr = Wk.tr.p; a.tb = Wk.tb.p;
-        a.pos = A->pos.p; a.next = A->next.p; a.fpos = hyp ? A->fpos.p : nullptr; a.flast = hyp ? A->flast.p : nullptr;
-        a.opt = Wk.opt.p; a.nnopt = Wk.nnopt.p; a.nlopt = Wk.nlopt.p; a.loc = Wk.loc.p; a.loc2 = Wk.loc2.p;
-        a.tileS = Wk.tileS.p; a.tileS2 = Wk.tileS2.p; a.taskR = Wk.taskR.p; a.tile_t0 = Wk.tile_t0.p;
         {
             // algorithmic bytes of one launch: per flattened step the stepped column's link
             // entries (4 B x N/n, plus 4 B x nonempty-rows/n for hyperedge costs), its colptr entry (8 B), the
             // candidate's previous-layer cost (8 B) and the task-descriptor share (offsets/B/anchor/row, amortised 8 B)
             ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * (avg_deg + self_deg) + 24.0));
-#define LP_ARGS R, T, a.offs, a.tB, a.tS0, a.tS0l, a.tr, a.tb, a.pos, a.next, a.fpos, a.flast, a.opt, a.nnopt, a.nlopt, a.loc, a.loc2, \
-                a.tileS, a.tileS2, a.taskR, a.tile_t0, W, M, alpha
+#define LP_ARGS R, T, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,           \
+                hyp ? A->flast.p : (const int32_t *)nullptr, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.loc.p, Wk.loc2.p, Wk.tileS.p, Wk.tileS2.p,     \
+                Wk.taskR.p, Wk.tile_t0.p, W, M, alpha
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, reinterpret_cast<Best<TC, false> *>(Wk.partR.p));
 #undef LP_ARGS
@@ -681,7 +676,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         }
         {
             ProfScope ps(PROF_EVAL, s, 0.0);
-#define OP_ARGS R, T, ntile, a.offs, a.tB, a.tS0, a.tS0l, a.tr, a.pos, a.loc, a.loc2, a.tile_t0, Wk.tilePS.p
+#define OP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.tilePS.p
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, Wk.tilePS2.p, W, M, alpha, Wk.partL.p);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, (const int64_t *)nullptr, W, M, alpha, reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
 #undef OP_ARGS
@@ -689,10 +684,10 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
-                               Wk.partL.p, Wk.partR.p, Wk.tr.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
+                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
-                               Wk.tr.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
+                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
         }
         CP_HIP(hipGetLastError());
     }
