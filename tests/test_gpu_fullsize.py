@@ -1,0 +1,98 @@
+"""Full-size checks on the GPU (BASELINE.json configs 2-4 shapes) through size-independent properties -- the
+literal oracle cannot run at these sizes:
+  * structure: sorted, spl[1] == 1, spl[end] == n+1, K parts / width limits;
+  * optimality of the total-cost DP: for a connectivity cost alpha=0 the optimum of sum_k f is known in closed form,
+    f(1, n+1) (all modular terms telescope and sum_k nets_k >= nets(all columns) with equality for one non-empty
+    part), so total_value(DP result) must equal the cost of the single part [1, n+1);  for the hyperedge-cut cost
+    (b_cut only) the optimum is 0;
+  * bounds sandwich c_lo <= bottleneck <= c_hi and monotonicity in eps for BisectCost;
+  * DP-optimal chunking never costs more than the Convex chunker's result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from util import cp
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(hip, n, colptr, rowval):
+    return hip.csr_from_device(n, n, int(rowval.numel()), colptr.data_ptr(), rowval.data_ptr())
+
+
+def test_config3_shape_total_dp_reaches_closed_form_optimum(hip):
+    from bench import gen_suitesparse_shaped
+    n, N = 10_000_000, 100_000_000
+    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 2, torch.device("cuda", 0))
+    h = _handle(hip, n, colptr, rowval)
+    try:
+        whole = np.array([1, n + 1], dtype=np.int64)
+        for mdl, K in ((cp.AffineConnectivityModel(0, 0, 0, 1), 6), (cp.AffineConnectivityModel(0, 10, 1, 100), 3),
+                       (cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), 3)):
+            mm = mdl.marshal()
+            spl = np.zeros(K + 1, dtype=np.int64)
+            assert hip.partition_dynamic(h, K, 0, 0, mm, None, None, 0, 0.0, spl) == 0, hip.last_error()
+            assert spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0)
+            rc, got = hip.objective(h, K, spl, mm, None, 0)
+            rc2, opt = hip.objective(h, 1, whole, mm, None, 0)
+            assert rc == 0 and rc2 == 0
+            assert got == opt, (mdl.kind, K, got, opt)
+        # K = 1 is the identity partition
+        spl = np.zeros(2, dtype=np.int64)
+        assert hip.partition_dynamic(h, 1, 0, 0, cp.AffineConnectivityModel(0, 0, 0, 1).marshal(), None, None, 0, 0.0, spl) == 0
+        assert spl.tolist() == [1, n + 1]
+    finally:
+        hip.csr_destroy(h)
+
+
+def test_config2_shape_bisect_bounds_and_eps_monotone(hip):
+    from bench import gen_suitesparse_shaped
+    n = 1_000_000
+    colptr, rowval = gen_suitesparse_shaped(n, 13 * n, 0xDEADBEEF + 1, torch.device("cuda", 0))
+    h = _handle(hip, n, colptr, rowval)
+    try:
+        K = 32
+        for mdl in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+            mm = mdl.marshal()
+            rc, lo, hi = hip.bound_stripe(h, K, mm)
+            assert rc == 0
+            prev = None
+            for eps in (0.1, 0.01, 0.001):
+                spl = np.zeros(K + 1, dtype=np.int64)
+                assert hip.partition_bisect_cost(h, K, mm, eps, 0, spl) == 0, hip.last_error()
+                assert spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0)
+                rc, b = hip.objective(h, K, spl, mm, None, 1)
+                assert lo <= b <= hi
+                if prev is not None:
+                    assert b <= prev * (1 + eps * 10)      # a tighter eps never loses more than the looser tolerance
+                prev = b
+    finally:
+        hip.csr_destroy(h)
+
+
+def test_config4_shape_width_limited_chunkers(hip):
+    from bench_configs import banded_dev
+    n = 100_000
+    colptr, rowval = banded_dev(n, 16, 0.5, 0xDEADBEEF + 4, torch.device("cuda", 0))
+    h = _handle(hip, n, colptr, rowval)
+    try:
+        f = cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w, w_table=9)
+        mm, wm = f.marshal(), cp.VertexCount().marshal()
+        res = {}
+        for name, fn in (("dynamic", hip.pack_dynamic), ("convex", hip.pack_convex)):
+            spl = np.zeros(n + 1, dtype=np.int64); Kout = np.zeros(1, dtype=np.int64)
+            assert fn(h, mm, None, wm, 8, 8.0, spl, Kout) == 0, hip.last_error()
+            Kc = int(Kout[0])
+            s = spl[:Kc + 1]
+            assert s[0] == 1 and s[-1] == n + 1 and np.all(np.diff(s) >= 1) and np.all(np.diff(s) <= 8)
+            rc, tot = hip.objective(h, Kc, np.ascontiguousarray(s), mm, None, 0)
+            res[name] = tot
+        assert res["dynamic"] <= res["convex"]              # the DP is optimal; the stack algorithm need not be on this model
+    finally:
+        hip.csr_destroy(h)
