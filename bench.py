@@ -178,6 +178,12 @@ def main():
         avg_ms = ex["ms"] / max(ex["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         b_alg = 8.0 * (n + 1 + N) + K * (n + 1) * 24.0 + 8.0 * (K + 1)      # SURVEY.md 8(d) whole-partition bytes
+        # HBM traffic of the dominant kernel from the PMC counters: collected by tools/pmc_lpass.sh under rocprofv3
+        # (FETCH_SIZE and WRITE_SIZE in separate passes) and committed under profiles/; valid for the default workload only
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_lpass.json")
+        if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
+            traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
         out = {
             "metric": "partitions/sec, DynamicTotalSplitter(AffineConnectivityModel{Int64}(0,0,0,1)), K=%d" % K,
             "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,7 +193,7 @@ def main():
                                    "n=%d rows, nnz=%d, K=%d; one independent partition per GPU" % (n, N, K),
                        "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
             "roofline": {"bound": "hbm", "kernel": "dp_lpass (k_lpass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": ex["launches"] / args.steps,
                          "alg_bytes_per_launch": bytes_per_launch,
                          "whole_path": {"alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9,
