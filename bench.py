@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--parts", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dbg", type=int, default=0, help="timing experiments only (wrong results)")
+    ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
+                    help="N>1: 'independent' = one partition per GPU (weak scaling, default); 'tiled' = ONE partition whose DP rows "
+                         "are tiled over the GPUs with an RCCL all_gather per layer (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +118,8 @@ def main():
     hip = _lib.HipBackend(device=dev.index)
     n, N, K = args.n, args.nnz, args.parts
     # independent partitions shard across ranks (weak scaling): every rank owns one matrix of the same shape
-    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 2 + 1000 * rank, dev)
+    tiled = args.mode == "tiled" and world > 1
+    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 2 + (0 if tiled else 1000 * rank), dev)
     N = int(rowval.numel())
     torch.cuda.synchronize()
     h = hip.csr_from_device(n, n, N, colptr.data_ptr(), rowval.data_ptr())
@@ -127,6 +131,10 @@ def main():
 
     def step():
         hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does
+        if tiled:
+            from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
+            spl[:] = partition_stripe_tiled(hip, h, n, K, cp.DynamicTotalSplitter(mdl), device=dev)
+            return
         rc = hip.partition_dynamic(h, K, 0, 0, mm, None, None, 0, 0.0, spl)
         if rc != 0:
             raise RuntimeError(f"cp_partition_dynamic -> {rc}: {hip.last_error()}")
@@ -168,7 +176,7 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * args.steps / dt
+        value = (1 if tiled else world) * args.steps / dt
         ex = prof["dp_lpass"]
         avg_deg = N / n
         # algorithmic bytes of one k_lpass launch, accumulated by the library per launch:
@@ -187,10 +195,10 @@ def main():
         out = {
             "metric": "partitions/sec, DynamicTotalSplitter(AffineConnectivityModel{Int64}(0,0,0,1)), K=%d" % K,
             "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "DynamicSplitter + ConnectivityCosts (lambda-1) on suitesparse_shaped CSR, "
-                                   "n=%d rows, nnz=%d, K=%d; one independent partition per GPU" % (n, N, K),
+                                   "n=%d rows, nnz=%d, K=%d; %s" % (n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
                        "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
             "roofline": {"bound": "hbm", "kernel": "dp_lpass (k_lpass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -22,6 +22,7 @@ SYMBOLS = [
     "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
+    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
 ]
 
 _lib = None
@@ -191,6 +192,29 @@ class HipBackend:
             raise NotImplementedError(f"cp_partwise -> {rc}: {self.last_error()}")
         n = npr.value
         return n, pios, prm[:n].copy(), pos[:n + 1].copy(), idx[:A.nnz].copy()
+
+    # ---- row-tiled DP (multi-GPU): see distributed.py
+    def dp_begin(self, A, K, combine, order, mm, row_lo, row_hi):
+        h = C.c_void_p()
+        rc = self.lib.cp_dp_begin(self._h(A), _i64(K), C.c_int32(combine), C.c_int32(order), mm.ptr, _i64(row_lo), _i64(row_hi), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_begin -> {rc}: {self.last_error()}")
+        return h
+
+    def dp_layer(self, dp, k, prev_ptr, cur_ptr):
+        rc = self.lib.cp_dp_layer(dp, _i64(k), C.c_void_p(prev_ptr), C.c_void_p(cur_ptr))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_layer -> {rc}: {self.last_error()}")
+
+    def dp_ptr_at(self, dp, k, jp):
+        out = C.c_int64()
+        rc = self.lib.cp_dp_ptr_at(dp, _i64(k), _i64(jp), C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_ptr_at -> {rc}: {self.last_error()}")
+        return out.value
+
+    def dp_destroy(self, dp):
+        self.lib.cp_dp_destroy(dp)
 
     # ---- measurement
     def prof_enable(self, on=True):

@@ -7,6 +7,9 @@
 
 using namespace cpk;
 
+namespace cpk { struct DpBase; }
+struct cp_dp_s { int32_t dtype; cpk::DpBase *impl; cp_csr_s *A; };
+
 namespace cpk {
 
 // ------------------------------------------------------------------ small kernels used by the drivers
@@ -176,7 +179,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     for (int64_t k = 2; k <= K; k++) {
         int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
         bool last = (k == K);
-        if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work);
+        if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work, 0, n);
         else dp_brute_layer<TC>(A, HM.d, alpha_of(k), combine, prevc, curc, pk, last ? n : 0, n);   // layer K: row n+1 only (:34)
         dump_layer(k, curc, last);
         std::swap(prevc, curc);
@@ -191,6 +194,91 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
         spl[k - 1] = v;
     }
     for (int64_t k = 0; k <= K; k++) spl_out[k] = spl[k] + 1;
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    return CP_OK;
+}
+
+// ------------------------------------------------------------------ row-tiled DP (one rank = one tile of rows per layer)
+// cp_dp_*: the same layers as run_dynamic, but a rank computes only rows [row_lo, row_hi) of every layer and the caller
+// completes the layer's cost vector with a collective (RCCL all_gather over xGMI) before the next layer.
+struct DpBase { virtual ~DpBase() {} };
+template <typename TC>
+struct DpRun : DpBase {
+    cp_csr_s *A = nullptr;
+    int64_t K = 0, rlo = 0, rhi = 0;          // 0-based inclusive row window
+    int32_t combine = 0, order = 0;
+    cp_model_t mdl{};
+    std::vector<TC> alpha_k_host;
+    HostModel<TC> HM;
+    bool fast = false, need_self = false;
+    void *work = nullptr;
+    DBuf<int32_t> ptr;                         // K x (n+1); only the tile rows of layers >= 2 are meaningful
+    ~DpRun() { if (work) dp_total_work_free<TC>(work); }
+    TC alpha_of(int64_t k) const
+    {
+        if (order == CP_ORDER_SPLITTER && !alpha_k_host.empty() && k >= 1 && k <= (int64_t)alpha_k_host.size()) return alpha_k_host[(size_t)k - 1];
+        return model_param<TC>(&mdl, CP_P_ALPHA);
+    }
+};
+
+template <typename TC>
+static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, const cp_model_t *model, int64_t row_lo, int64_t row_hi,
+                        DpBase **out)
+{
+    std::unique_ptr<DpRun<TC>> D(new DpRun<TC>());
+    int64_t n = A->n;
+    D->A = A; D->K = K; D->combine = combine; D->order = order; D->mdl = *model;
+    D->rlo = row_lo - 1; D->rhi = row_hi - 2;
+    if (model->alpha_k && model->n_alpha_k > 0) {
+        D->alpha_k_host.assign((const TC *)model->alpha_k, (const TC *)model->alpha_k + model->n_alpha_k);
+        D->mdl.alpha_k = D->alpha_k_host.data();
+    }
+    D->need_self = model->kind == CP_MODEL_HYPEREDGE_CUT;
+    D->fast = combine == CP_COMBINE_SUM && fast_total_ok(model) && !g_opt_force_brute;
+    if (!D->fast)
+        CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
+                   "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
+    ensure_links(A);
+    if (D->need_self) ensure_self(A);
+    build_dev_model<TC>(&D->mdl, D->HM, A->stream);
+    D->ptr.alloc((size_t)K * (size_t)(n + 1));
+    CP_HIP(hipMemsetAsync(D->ptr.p, 0, D->ptr.bytes(), A->stream));
+    if (D->fast) D->work = dp_total_work_new<TC>();
+    CP_HIP(hipStreamSynchronize(A->stream));
+    *out = D.release();
+    return CP_OK;
+}
+
+template <typename TC>
+static int32_t dp_layer(DpRun<TC> *D, int64_t k, const TC *prev, TC *cur)
+{
+    cp_csr_s *A = D->A;
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    size_t n1 = (size_t)n + 1;
+    int32_t *pk = D->ptr.p + (size_t)(k - 1) * n1;
+    if (k == 1) {                                  // every rank computes the whole first layer: a column scan, no exchange needed
+        const cp_model_t *mdl = &D->mdl;
+        bool has_nets = mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_HYPEREDGE_CUT || mdl->kind == CP_MODEL_COLBLOCK;
+        DBuf<int32_t> cnt0((size_t)(n > 0 ? n : 1));
+        DBuf<int64_t> firsts(n1), scratch;
+        if (has_nets) {
+            if (n > 0) hipLaunchKernelGGL(k_col_count_prev_lt, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, A->pos.p, A->prev.p, 0, cnt0.p, n);
+            exclusive_scan_i32(cnt0.p, firsts.p, n, scratch, s);
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_layer1<TC>), dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, A->pos.p,
+                           has_nets ? firsts.p : nullptr, D->need_self ? A->lpos.p : nullptr, D->HM.d, D->alpha_of(1), cur, pk);
+        CP_HIP(hipGetLastError());
+        CP_HIP(hipStreamSynchronize(s));
+        return CP_OK;
+    }
+    CP_REQUIRE(prev && cur && k >= 2 && k <= D->K, CP_EINVAL, "bad layer");
+    int64_t rlo = D->rlo < 0 ? 0 : D->rlo, rhi = D->rhi > n ? n : D->rhi;
+    if (rhi >= rlo) {
+        if (D->fast) dp_total_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, D->work, rlo, rhi);
+        else dp_brute_layer<TC>(A, D->HM.d, D->alpha_of(k), D->combine, prev, cur, pk, rlo, rhi);
+    }
     CP_HIP(hipStreamSynchronize(s));
     prof_collect();
     return CP_OK;
@@ -495,6 +583,67 @@ int32_t cp_link_array(cp_csr_t A, int64_t *out)
         for (int64_t q = 0; q < A->N; q++) out[q] = (A->n + 1) - ((int64_t)h[q] + 1);   // idx'[q] = (n+1) - hst[i]
         return CP_OK;
     });
+}
+
+// ---- row-tiled DP across ranks (multi-GPU): see include/chainpart.h
+int32_t cp_dp_begin(cp_csr_t A, int64_t K, int32_t combine, int32_t order, const cp_model_t *model, int64_t row_lo, int64_t row_hi,
+                    cp_dp_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && out && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        CP_REQUIRE(row_lo >= 1 && row_hi >= row_lo && row_hi <= A->n + 2, CP_EINVAL, "row tile must satisfy 1 <= row_lo <= row_hi <= n+2");
+        CP_REQUIRE(model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT ||
+                       model->kind == CP_MODEL_COLBLOCK, CP_EUNSUPPORTED, "model kind has no device DP path");
+        CP_HIP(hipSetDevice(A->device));
+        DpBase *impl = nullptr;
+        int32_t rc = model->dtype == CP_I64 ? dp_begin<int64_t>(A, K, combine, order, model, row_lo, row_hi, &impl)
+                                            : dp_begin<double>(A, K, combine, order, model, row_lo, row_hi, &impl);
+        if (rc != CP_OK) return rc;
+        cp_dp_s *h = new cp_dp_s();
+        h->dtype = model->dtype; h->impl = impl; h->A = A;
+        *out = h;
+        return CP_OK;
+    });
+}
+
+int32_t cp_dp_layer(cp_dp_t dp, int64_t k, const void *cst_prev_device, void *cst_cur_device)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(dp && cst_cur_device && k >= 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(dp->A->device));
+        if (dp->dtype == CP_I64) return dp_layer<int64_t>(static_cast<DpRun<int64_t> *>(dp->impl), k, (const int64_t *)cst_prev_device, (int64_t *)cst_cur_device);
+        return dp_layer<double>(static_cast<DpRun<double> *>(dp->impl), k, (const double *)cst_prev_device, (double *)cst_cur_device);
+    });
+}
+
+int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(dp && out && k >= 1 && jp >= 1 && jp <= dp->A->n + 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(dp->A->device));
+        int64_t rlo, rhi; DBuf<int32_t> *ptr; int64_t K;
+        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
+        else { auto *D = static_cast<DpRun<double> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
+        CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+        *out = 0;
+        if (k == 1) { *out = 1; return CP_OK; }                 // ptr[:, 1] == 1 on every rank
+        int64_t r = jp - 1;
+        if (r < rlo || r > rhi) return CP_OK;                   // another rank owns this row
+        int32_t v = 0;
+        CP_HIP(hipMemcpyAsync(&v, ptr->p + (size_t)(k - 1) * (size_t)(dp->A->n + 1) + (size_t)r, sizeof(int32_t), hipMemcpyDeviceToHost, dp->A->stream));
+        CP_HIP(hipStreamSynchronize(dp->A->stream));
+        *out = (int64_t)v + 1;
+        return CP_OK;
+    });
+}
+
+int32_t cp_dp_destroy(cp_dp_t dp)
+{
+    if (!dp) return CP_OK;
+    (void)hipSetDevice(dp->A->device);
+    delete dp->impl;
+    delete dp;
+    return CP_OK;
 }
 
 }  // extern "C"

@@ -7,7 +7,8 @@ namespace cpk {
 
 // one layer of the total-cost DP by the O(n log^2 n) scheme (dp_total.hip)
 template <typename TC>
-void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work);
+void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work,
+                    int64_t rlo, int64_t rhi);      // computes rows r in [rlo, rhi] (0-based); the full range is [0, n]
 template <typename TC> void *dp_total_work_new();
 template <typename TC> void dp_total_work_free(void *w);
 

@@ -32,17 +32,20 @@ constexpr int LT = 256;          // steps per tile (one wave owns one tile)
 constexpr int NBMAX = 31;        // bit planes (n < 2^30)
 
 struct RoundDesc {
-    int32_t isA, tau, nbits, _pad;
+    int32_t isA, tau, nbits, nextra;
     int64_t n, ntask;
-    int64_t tbase[36];
+    int64_t tbase[36];          // tau rounds: tasks of bit plane b occupy [tbase[b], tbase[b+1])
+    int64_t tskip[36];          // ... and start at linear index tskip[b] of that plane (row-tiled runs skip rows left of the tile)
+    int64_t a_r0, a_nmain;      // round A: rows a_r0 .. a_r0 + a_nmain - 1, then the `extra` rows (ancestors outside the tile)
+    int64_t extra[64];
 };
 
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
 {
-    if (R.isA) { r = t + 1; b = __ffsll((long long)r) - 1; return; }
+    if (R.isA) { r = t < R.a_nmain ? R.a_r0 + t : R.extra[t - R.a_nmain]; b = __ffsll((long long)r) - 1; return; }
     int bb = R.tau + 1;
     while (t >= R.tbase[bb + 1]) bb++;
-    int64_t l = t - R.tbase[bb];
+    int64_t l = t - R.tbase[bb] + R.tskip[bb];
     int sh = bb - R.tau - 1;
     int64_t base = l >> sh, v = l & (((int64_t)1 << sh) - 1);
     r = (base << (bb + 1)) | ((int64_t)1 << bb) | (((v << 1) | 1) << R.tau);
@@ -55,11 +58,13 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 // `ge` selects the comparison: 0: link < threshold (nets: prev[q] < B); 1: link >= threshold (self nets: first >= B
 // over the rows bucketed by their LAST column).
 template <bool ge>
-__global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
                                                      int32_t *__restrict__ cr)
 {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nrows) return;
+    u += u0;
     int64_t r = ((u << 1) | 1) << tau;
     if (r > n) return;
     int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
 
 // Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
 template <bool ge>
-__global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t nrows, int chunks_per_row, int ch_cols,
+__global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, int chunks_per_row, int ch_cols,
                                                     const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
                                                     const int32_t *__restrict__ opt, int32_t *__restrict__ cr)
 {
@@ -92,6 +97,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     int64_t u = w / chunks_per_row;
     int ck = (int)(w - u * chunks_per_row);
     if (u >= nrows) return;
+    u += u0;
     int64_t r = ((u << 1) | 1) << tau;
     if (r > n) return;
     int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
@@ -516,14 +522,14 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
 
 // ------------------------------------------------------------------ combine the per-bit winners of every row
 template <typename TC>
-__global__ void __launch_bounds__(256) k_combine(int64_t n, int nbits, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t rhi, int nbits, const int64_t *__restrict__ pos,
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                  const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  TC *__restrict__ cst, int32_t *__restrict__ ptr)
 {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > n) return;
+    int64_t r = rlo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rhi) return;
     int64_t n1 = n + 1;
     TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
     int64_t bp = r;
@@ -552,48 +558,88 @@ struct LayerWork {
     int64_t max_tasks = 0;
 };
 
-static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n)
+// number of rows r <= x of the form (base << (b+1)) | (1 << b) | ((2v+1) << tau): the rows with ctz == tau whose bit b is set
+static int64_t count_rows(int b, int tau, int64_t x)
+{
+    if (x < 0) return 0;
+    int sh = b - tau - 1;
+    int64_t V = (int64_t)1 << sh;
+    int64_t nfull = (x + ((int64_t)1 << tau)) >> (b + 1);
+    int64_t cnt = nfull * V;
+    int64_t y = x - (nfull << (b + 1)) - ((int64_t)1 << b);
+    if (y >= ((int64_t)1 << tau)) cnt += ((y >> tau) + 1) >> 1;
+    return cnt;
+}
+
+// Rows computed by a run restricted to the row tile [rlo, rhi]: every row r with
+//     r - 2^ctz(r) <= rhi  and  r + 2^ctz(r) >= rlo
+// -- the tile plus the O(log n) tree ancestors its rows take their candidate bounds from (closed under ancestors).
+static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, int64_t rlo, int64_t rhi)
 {
     memset(&R, 0, sizeof(R));
     R.isA = isA; R.tau = tau; R.nbits = nbits; R.n = n;
-    if (isA) { R.ntask = n; return; }
+    if (isA) {
+        int64_t r0 = rlo > 1 ? rlo : 1, r1 = rhi < n ? rhi : n;
+        R.a_r0 = r0; R.a_nmain = r1 >= r0 ? r1 - r0 + 1 : 0;
+        R.nextra = 0;
+        for (int b = 0; b < nbits; b++) {            // rows with ctz == b just outside the tile
+            int64_t step = (int64_t)1 << b;
+            // left of the tile: r in [rlo - 2^b, rlo) ; right: r in (rhi, rhi + 2^b]
+            for (int side = 0; side < 2; side++) {
+                int64_t lo = side == 0 ? rlo - step : rhi + 1, hi = side == 0 ? rlo - 1 : rhi + step;
+                if (lo < 1) lo = 1;
+                if (hi > n) hi = n;
+                for (int64_t r = ((lo + step - 1) >> b) << b; r <= hi; r += step)
+                    if (r >= 1 && ((r >> b) & 1) && R.nextra < 64) R.extra[R.nextra++] = r;      // ctz(r) == b exactly
+            }
+        }
+        R.ntask = R.a_nmain + R.nextra;
+        return;
+    }
+    int64_t rmin = rlo - ((int64_t)1 << tau), rmax = rhi + ((int64_t)1 << tau);
+    if (rmax > n) rmax = n;
     int64_t acc = 0;
     for (int b = 0; b <= tau; b++) R.tbase[b] = 0;
     for (int b = tau + 1; b < nbits; b++) {
         R.tbase[b] = acc;
-        int sh = b - tau - 1;
-        int64_t V = (int64_t)1 << sh;
-        int64_t nfull = (n + ((int64_t)1 << tau)) >> (b + 1);
-        int64_t cnt = nfull * V;
-        int64_t x = n - (nfull << (b + 1)) - ((int64_t)1 << b);
-        if (x >= ((int64_t)1 << tau)) cnt += ((x >> tau) + 1) >> 1;
-        acc += cnt;
+        int64_t skip = count_rows(b, tau, rmin - 1);
+        int64_t cnt = count_rows(b, tau, rmax) - skip;
+        R.tskip[b] = skip;
+        acc += cnt > 0 ? cnt : 0;
     }
     for (int b = nbits; b < 36; b++) R.tbase[b] = acc;
     R.ntask = acc;
 }
 
 // right part of one round for one counter: rows with ctz == tau stream their 2^tau columns once for all bit planes
-static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n, const int64_t *cpos, const int32_t *link, int ge,
-                         const int32_t *opt, int32_t *cr)
+static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n, int64_t rlo, int64_t rhi, const int64_t *cpos,
+                         const int32_t *link, int ge, const int32_t *opt, int32_t *cr)
 {
     int tau = R.tau;
-    int64_t nrows = ((n >> tau) + 1) >> 1;                     // rows (2u+1)<<tau <= n
+    int64_t rmin = rlo - ((int64_t)1 << tau), rmax = rhi + ((int64_t)1 << tau);
+    if (rmax > n) rmax = n;
+    if (rmin < 0) rmin = 0;
+    // rows (2u+1)<<tau in [rmin, rmax]
+    int64_t u0 = rmin <= 0 ? 0 : (((rmin - 1) >> tau) + 1) >> 1;       // #rows < rmin
+    int64_t u1 = ((rmax >> tau) + 1) >> 1;                              // #rows <= rmax
+    int64_t nrows = u1 - u0;
+    if (nrows <= 0) return;
     if (tau <= 3) {
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, cpos, link, opt, cr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, cpos, link, opt, cr);
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
     } else {
         int ch_cols = 256;
         int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
         if (cpr == 1) ch_cols = 1 << tau;
         int64_t waves = nrows * cpr;
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
     }
 }
 
 template <typename TC>
-void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_)
+void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_,
+                    int64_t rlo, int64_t rhi)
 {
     auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
     hipStream_t s = A->stream;
@@ -608,7 +654,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
         if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
         int64_t mx = n;
-        for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n); if (R.ntask > mx) mx = R.ntask; }
+        for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n, 0, n); if (R.ntask > mx) mx = R.ntask; }
         Wk.max_tasks = mx > 0 ? mx : 1;
         size_t mt = (size_t)Wk.max_tasks;
         Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
@@ -618,8 +664,8 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
-        if (rd == 0) make_round(R, true, 0, nbits, n);
-        else make_round(R, false, nbits - rd, nbits, n);
+        if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi);
+        else make_round(R, false, nbits - rd, nbits, n, rlo, rhi);
         if (R.ntask <= 0) continue;
         if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
@@ -628,8 +674,8 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
                 hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
                                    Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
                                    (int32_t *)nullptr);
-            launch_rpass(s, R, nbits, n, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
-            if (hyp) launch_rpass(s, R, nbits, n, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
+            launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
+            if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
         {
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
@@ -693,7 +739,9 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     }
     {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, nbits, A->pos.p,
+        int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
+        if (c1 >= c0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(c1 - c0 + 1, 256)), dim3(256), 0, s, n, c0, c1, nbits, A->pos.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
     CP_HIP(hipGetLastError());
@@ -702,8 +750,8 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> void dp_total_work_free(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
 
-template void dp_total_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, void *);
-template void dp_total_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, void *);
+template void dp_total_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, void *, int64_t, int64_t);
+template void dp_total_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, void *, int64_t, int64_t);
 template void *dp_total_work_new<int64_t>();
 template void *dp_total_work_new<double>();
 template void dp_total_work_free<int64_t>(void *);

@@ -108,6 +108,22 @@ int32_t cp_pack_equi(int64_t n, int64_t w, int64_t *spl_out /* cld(n,w)+1 */, in
 int32_t cp_dynamic_tables(cp_csr_t csr, int64_t K, int32_t combine, const cp_model_t *model,
                           const cp_rowpart_t *Pi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
 
+/* ---- row-tiled DP: one process per GPU, the layer's cost vector is completed by the caller's collective ----
+ * The rows j' of every DP layer (DynamicSplitter.jl:33-46: all cst[j',k] of a layer depend only on layer k-1) are
+ * tiled contiguously over the ranks.  Rank g calls cp_dp_begin with its tile [row_lo, row_hi) (1-based, half-open,
+ * tiles cover 1..n+1), then for k = 1..K: cp_dp_layer(dp, k, prev, cur) -- layer 1 is computed in full by every rank;
+ * for k >= 2 it fills cur[row_lo-1 .. row_hi-2] from the COMPLETE previous layer `prev` -- followed by an all_gather of
+ * the tile slices (torch.distributed / RCCL over xGMI) so that `cur` is complete everywhere.  cst buffers are
+ * caller-owned device arrays of n+1 cost elements (int64 or double like the model).  unravel_splits
+ * (DynamicSplitter.jl:89-99) asks the owner of each row: cp_dp_ptr_at returns ptr[j',k] (1-based) on the owning rank
+ * and 0 elsewhere, so a MAX all_reduce of one integer per layer walks the chain. */
+typedef struct cp_dp_s *cp_dp_t;
+int32_t cp_dp_begin(cp_csr_t csr, int64_t K, int32_t combine, int32_t order, const cp_model_t *model,
+                    int64_t row_lo, int64_t row_hi, cp_dp_t *out);
+int32_t cp_dp_layer(cp_dp_t dp, int64_t k, const void *cst_prev_device, void *cst_cur_device);
+int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out);
+int32_t cp_dp_destroy(cp_dp_t dp);
+
 /* ---- execution control / measurement ---- */
 /* run subsequent launches of this csr on an existing hipStream_t (e.g. torch's current stream) */
 int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
