@@ -37,39 +37,40 @@ __global__ void k_layer1(int64_t n, const int64_t *__restrict__ pos, const int64
     ptr[r] = 0;
 }
 
-// counts for one (p, r) range per block: nets = #{q in cols [p,r) : prev[q] < p},
-// selfnets = #{rows with first in [p,r) and last < r}
+// counts for (p, r) ranges: nets = #{q in cols [p,r) : prev[q] < p}, selfnets = #{rows with first in [p,r) and last < r}.
+// gridDim.y blocks share one query (grid-stride over its entries) and combine with one atomic per block.
 __global__ void __launch_bounds__(256) k_range_counts(int64_t nq, const int64_t *__restrict__ P, const int64_t *__restrict__ Rr,
                                                       const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
                                                       const int64_t *__restrict__ fpos, const int32_t *__restrict__ flast,
-                                                      int64_t *__restrict__ nets, int64_t *__restrict__ selfnets)
+                                                      unsigned long long *__restrict__ nets, unsigned long long *__restrict__ selfnets)
 {
     int64_t i = blockIdx.x;
     if (i >= nq) return;
     __shared__ int64_t sh[256];
     int64_t p = P[i], r = Rr[i];
+    int64_t stride = (int64_t)gridDim.y * 256, start = (int64_t)blockIdx.y * 256 + threadIdx.x;
     int64_t c = 0;
     if (r > p) {
         int64_t q0 = pos[p], q1 = pos[r];
         int32_t thr = (int32_t)p;
-        for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) c += (prev[q] < thr);
+        for (int64_t q = q0 + start; q < q1; q += stride) c += (prev[q] < thr);
     }
     sh[threadIdx.x] = c;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < (unsigned)o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) nets[i] = sh[0];
+    if (threadIdx.x == 0 && sh[0]) atomicAdd(&nets[i], (unsigned long long)sh[0]);
     __syncthreads();
     if (selfnets) {
         c = 0;
         if (r > p) {
             int64_t s0 = fpos[p], s1 = fpos[r];
             int32_t thr = (int32_t)r;
-            for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) c += (flast[s] < thr);
+            for (int64_t s = s0 + start; s < s1; s += stride) c += (flast[s] < thr);
         }
         sh[threadIdx.x] = c;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < (unsigned)o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) selfnets[i] = sh[0];
+        if (threadIdx.x == 0 && sh[0]) atomicAdd(&selfnets[i], (unsigned long long)sh[0]);
     }
 }
 
@@ -307,10 +308,15 @@ static int32_t run_oracle_eval(cp_csr_s *A, const cp_model_t *mdl, int64_t nq, c
     if (k) { dK.alloc((size_t)nq); CP_HIP(hipMemcpyAsync(dK.p, k, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, s)); }
     if (has_nets) {
         dN.alloc((size_t)nq);
-        if (need_self) dS.alloc((size_t)nq);
+        CP_HIP(hipMemsetAsync(dN.p, 0, dN.bytes(), s));
+        if (need_self) { dS.alloc((size_t)nq); CP_HIP(hipMemsetAsync(dS.p, 0, dS.bytes(), s)); }
+        int64_t per = nq > 0 ? A->N / nq : 0;
+        unsigned gy = (unsigned)(per / 65536 + 1);                   // ~64k entries per block
+        if (gy > 2048) gy = 2048;
         ProfScope ps(PROF_QUERY, s, 0.0);
-        hipLaunchKernelGGL(k_range_counts, dim3((unsigned)nq), dim3(256), 0, s, nq, dP.p, dR.p, A->pos.p, A->prev.p,
-                           need_self ? A->fpos.p : nullptr, need_self ? A->flast.p : nullptr, dN.p, need_self ? dS.p : nullptr);
+        hipLaunchKernelGGL(k_range_counts, dim3((unsigned)nq, gy), dim3(256), 0, s, nq, dP.p, dR.p, A->pos.p, A->prev.p,
+                           need_self ? A->fpos.p : nullptr, need_self ? A->flast.p : nullptr, (unsigned long long *)dN.p,
+                           need_self ? (unsigned long long *)dS.p : nullptr);
     }
     HostModel<TC> HM;
     build_dev_model<TC>(mdl, HM, s);

@@ -76,10 +76,15 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
         cnt[b] = 0;
     }
     int64_t q0 = pos[rL], q1 = pos[r];
-    for (int64_t q = q0; q < q1; q++) {
-        int32_t v = prev[q];
+    const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
+    for (int64_t q = q0; q < q1; q += 4) {                     // four independent loads in flight per lane
+        int32_t v0 = prev[q], v1 = q + 1 < q1 ? prev[q + 1] : NEVER, v2 = q + 2 < q1 ? prev[q + 2] : NEVER, v3 = q + 3 < q1 ? prev[q + 3] : NEVER;
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
+        for (int b = 0; b < NBMAX; b++) {
+            if (b <= tau || b >= nbits) continue;              // wave-uniform
+            int32_t t = thr[b];
+            cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
+        }
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++)
@@ -114,7 +119,10 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     for (int64_t q = q0 + lane; q < q1; q += 64) {
         int32_t v = prev[q];
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
+        for (int b = 0; b < NBMAX; b++) {
+            if (b <= tau || b >= nbits) continue;              // wave-uniform
+            cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
+        }
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
@@ -484,35 +492,34 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
 }
 
 // a task whose steps span several tiles: combine the head tile's partial with the partials of the tiles it covers
+// (one wave per tile; only head tiles of spanning tasks do work)
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
                                              const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
                                              const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
                                              int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
 {
-    int64_t tile = blockIdx.x;
+    int lane = threadIdx.x & 63;
+    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
     int64_t t = taskR[tile];
     if (t < 0) return;
-    __shared__ Best<TC, HYP> s_B[256];
     int64_t end_tile = (offs[t + 1] - 1) / LT;
     Best<TC, HYP> acc; best_clear(acc);
-    for (int64_t k = tile + 1 + threadIdx.x; k <= end_tile; k += 256) {
+    for (int64_t k = tile + 1 + lane; k <= end_tile; k += 64) {
         Best<TC, HYP> c = partL[k];
         bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
         if (take) acc = c;
     }
-    s_B[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < (unsigned)o) {
-            Best<TC, HYP> x = s_B[threadIdx.x], y = s_B[threadIdx.x + o];
-            bool takey = (x.p < 0) ? (y.p >= 0) : (y.p >= 0 && (y.v < x.v || (y.v == x.v && y.p > x.p)));
-            if (takey) s_B[threadIdx.x] = y;
-        }
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        int src = (lane + o) & 63;
+        Best<TC, HYP> c; best_clear(c); c.v = shfl64(acc.v, src); c.p = __shfl(acc.p, src); c.nn = __shfl(acc.nn, src);
+        if (HYP) best_set_nl(c, __shfl(best_nl(acc), src));
+        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+        if (lane + o < 64 && take) acc = c;
     }
-    if (threadIdx.x == 0) {
-        Best<TC, HYP> res = better(partR[tile], s_B[0]);     // the head tile holds the larger p: wins ties
+    if (lane == 0) {
+        Best<TC, HYP> res = better(partR[tile], acc);   // the head tile holds the larger p: wins ties
         int64_t r = tdesc[t].z; int b = tb[t];
         opt[(int64_t)b * n1 + r] = res.p;
         nnopt[(int64_t)b * n1 + r] = res.nn;
@@ -729,9 +736,9 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         }
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
                                Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3((unsigned)ntile), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
                                Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
         }
