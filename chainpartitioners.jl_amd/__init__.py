@@ -12,6 +12,8 @@ from .models import (AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCu
                      DynamicBottleneckSplitter, DynamicTotalChunker, DynamicBottleneckChunker,
                      ReferenceTotalSplitter, ReferenceBottleneckSplitter, ReferenceTotalChunker,
                      BisectCostBottleneckSplitter, FlipBisectCostBottleneckSplitter,
+                     BisectIndexBottleneckSplitter, FlipBisectIndexBottleneckSplitter,
+                     LazyBisectCostBottleneckSplitter,
                      ConvexTotalChunker, ConvexTotalSplitter)
 from . import _lib  # noqa: F401
 from .api import (partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401

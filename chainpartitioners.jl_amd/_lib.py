@@ -23,6 +23,7 @@ SYMBOLS = [
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
+    "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost",
 ]
 
 _lib = None
@@ -121,6 +122,12 @@ class HipBackend:
 
     def partition_bisect_cost(self, A, K, mm, eps, flip, spl):
         return self.lib.cp_partition_bisect_cost(self._h(A), _i64(K), mm.ptr, C.c_double(eps), C.c_int32(flip), _p(spl))
+
+    def partition_bisect_index(self, A, K, mm, flip, spl):
+        return self.lib.cp_partition_bisect_index(self._h(A), _i64(K), mm.ptr, C.c_int32(flip), _p(spl))
+
+    def partition_lazy_bisect_cost(self, A, K, mm, eps, spl):
+        return self.lib.cp_partition_lazy_bisect_cost(self._h(A), _i64(K), mm.ptr, C.c_double(eps), _p(spl))
 
     def pack_convex(self, A, mm, rp, wm, wi, wf, spl, Kout):
         return self.lib.cp_pack_convex(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,

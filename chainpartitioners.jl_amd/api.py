@@ -133,6 +133,22 @@ def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) ->
         rc = b.partition_bisect_cost(A, K, mm, method.eps, method.flip, spl)
         _check(rc, "partition_stripe(BisectCost)", b)
         return SplitPartition(K, spl)
+    if isinstance(method, M.BisectIndexBottleneckSplitter):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, None)
+        if wm is not None:
+            raise NotImplementedError("BisectIndex on a ConstrainedCost errors in the reference (Costs.jl:150)")
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_bisect_index(A, K, mm, method.flip, spl)
+        _check(rc, "partition_stripe(BisectIndex)", b)
+        return SplitPartition(K, spl)
+    if isinstance(method, M.LazyBisectCostBottleneckSplitter):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, None)
+        if wm is not None:
+            raise NotImplementedError("LazyBisectCost on a ConstrainedCost has no method in the reference")
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_lazy_bisect_cost(A, K, mm, method.eps, spl)
+        _check(rc, "partition_stripe(LazyBisectCost)", b)
+        return SplitPartition(K, spl)
     if isinstance(method, M.ConvexTotalSplitter):
         mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
         spl = np.zeros(K + 1, dtype=np.int64)

@@ -25,6 +25,15 @@ __device__ __forceinline__ bool le_f64(int64_t v, double c)
     return v <= (int64_t)floor(c);
 }
 __device__ __forceinline__ bool le_f64(double v, double c) { return v <= c; }
+__device__ __forceinline__ bool le_f64(int64_t v, int64_t c) { return v <= c; }
+// v < c with v::Int64, c::Float64, exactly
+__device__ __forceinline__ bool lt_f64(int64_t v, double c)
+{
+    if (c != c) return false;
+    if (c >= 9223372036854775808.0) return true;
+    if (c <= -9223372036854775808.0) return false;
+    return v < (int64_t)ceil(c);
+}
 
 template <typename TC>
 struct OracleDev {
@@ -45,8 +54,8 @@ __device__ __forceinline__ TC oracle_eval_dev(const OracleDev<TC> &O, int64_t j,
     return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, nn, (int64_t)0);
 }
 
-template <typename TC>
-__device__ int64_t search6(const OracleDev<TC> &O, int64_t j, int64_t lo, int64_t hi, int64_t k, double c, int flip, int lane)
+template <typename TC, typename CT>
+__device__ int64_t search6(const OracleDev<TC> &O, int64_t j, int64_t lo, int64_t hi, int64_t k, CT c, int flip, int lane)
 {
     if (lo < j) lo = j;                                   // j'_lo = max(j, j'_lo)  (:17)
     while (lo <= hi) {
@@ -126,8 +135,92 @@ __global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, doubl
     if (lane == 0) *nprobes = probes;
 }
 
+// ------------------------------------------------------------------ BisectIndexBottleneckSplitter.jl:5-83, flip :85-166
+// c_lo / c_hi start as Float64 (bound_stripe ./ 1, :39) and are later overwritten with cost values of type Tc (:60, :64);
+// Int64 costs keep the two representations apart so that every comparison is exact.
+template <typename TC> struct IdxBound;
+template <> struct IdxBound<double> {
+    double v;
+    __device__ void init(double d) { v = d; }
+    __device__ void set(double c) { v = c; }
+    __device__ bool le_c(double c) const { return v <= c; }        // bound <= c
+    __device__ bool c_lt(double c) const { return c < v; }         // c < bound
+};
+template <> struct IdxBound<int64_t> {
+    double f; int64_t i; int is_int;
+    __device__ void init(double d) { f = d; i = 0; is_int = 0; }
+    __device__ void set(int64_t c) { i = c; is_int = 1; }
+    __device__ bool le_c(int64_t c) const { return is_int ? i <= c : !lt_f64(c, f); }
+    __device__ bool c_lt(int64_t c) const { return is_int ? c < i : lt_f64(c, f); }
+};
+
 template <typename TC>
-int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, double c_hi, double eps, int flip, int64_t *spl_out)
+__global__ void __launch_bounds__(64) k_bisect_index(OracleDev<TC> O, int64_t K, double c_lo0, double c_hi0, int flip,
+                                                     int64_t *__restrict__ spl_lo, int64_t *__restrict__ spl_hi, int64_t *__restrict__ spl,
+                                                     int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
+{
+    int lane = threadIdx.x;
+    int64_t n = O.n;
+    for (int64_t k = 1; k <= K + 1; k++) { spl_lo[k - 1] = 1; spl_hi[k - 1] = n + 1; spl[k - 1] = 0; }
+    spl_lo[K] = n + 1;
+    spl_hi[0] = 1;
+    spl[0] = 1;
+    spl[K] = n + 1;
+    IdxBound<TC> clo, chi;
+    clo.init(c_lo0); chi.init(c_hi0);
+    int64_t probes = 0;
+    for (int64_t k = 1; k <= K; k++) {
+        int64_t jhi = spl_hi[k];
+        int64_t jlo = spl[k - 1] > spl_lo[k] ? spl[k - 1] : spl_lo[k];
+        while (jlo <= jhi) {
+            int64_t jp = (int64_t)(((uint64_t)(jlo + jhi)) >> 1);
+            TC c = oracle_eval_dev(O, spl[k - 1], jp, k);
+            if (clo.le_c(c) && chi.c_lt(c)) {                  // c_lo <= c < c_hi
+                probes++;
+                bool chk = true;
+                spl[k] = jp;
+                for (int64_t kk = k + 1; kk <= K - 1; kk++) {
+                    int64_t j = spl[kk - 1];
+                    int64_t rr = search6(O, j, spl_lo[kk], spl_hi[kk], kk, c, flip, lane);
+                    spl[kk] = rr;
+                    if (!flip) {
+                        if (rr < j) { chk = false; for (int64_t t = kk + 1; t <= K; t++) spl[t - 1] = j; break; }
+                    } else {
+                        if (rr > n + 1) { chk = false; for (int64_t t = kk + 1; t <= K; t++) spl[t - 1] = n + 1; break; }
+                    }
+                }
+                bool ok = chk && le_f64(oracle_eval_dev(O, spl[K - 1], spl[K], K), c);
+                int64_t *dst;
+                if (ok) {
+                    chi.set(c);
+                    if (!flip) { jhi = jp - 1; dst = spl_hi; } else { jlo = jp + 1; dst = spl_lo; }
+                } else {
+                    clo.set(c);
+                    if (!flip) { jlo = jp + 1; dst = spl_lo; } else { jhi = jp - 1; dst = spl_hi; }
+                }
+                for (int64_t t = 0; t <= K; t++) dst[t] = spl[t];
+            } else if (!chi.c_lt(c)) {                         // c >= c_hi
+                if (!flip) jhi = jp - 1; else jlo = jp + 1;
+            } else {
+                if (!flip) jlo = jp + 1; else jhi = jp - 1;
+            }
+        }
+        if (!flip) {
+            if (jhi < spl[k - 1]) break;                       // :74
+            spl[k] = jhi;
+        } else {
+            if (jlo > n + 1) break;                            // :157
+            spl[k] = jlo;
+        }
+    }
+    const int64_t *src = flip ? spl_lo : spl_hi;
+    for (int64_t k = lane; k <= K; k += 64) out[k] = src[k];
+    if (lane == 0) *nprobes = probes;
+}
+
+template <typename TC>
+int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, double c_hi, double eps, int flip, int64_t *spl_out,
+                   bool by_index = false)
 {
     hipStream_t s = A->stream;
     HostModel<TC> HM;
@@ -140,7 +233,8 @@ int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, d
     int64_t *d_lo = buf.p, *d_hi = buf.p + (K + 1), *d_spl = buf.p + 2 * (K + 1), *d_out = buf.p + 3 * (K + 1), *d_np = buf.p + 4 * (K + 1);
     {
         ProfScope ps(PROF_BISECT, s, 0.0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect<TC>), dim3(1), dim3(64), 0, s, O, K, c_lo, c_hi, eps, flip, d_lo, d_hi, d_spl, d_out, d_np);
+        if (by_index) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect_index<TC>), dim3(1), dim3(64), 0, s, O, K, c_lo, c_hi, flip, d_lo, d_hi, d_spl, d_out, d_np);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect<TC>), dim3(1), dim3(64), 0, s, O, K, c_lo, c_hi, eps, flip, d_lo, d_hi, d_spl, d_out, d_np);
     }
     CP_HIP(hipGetLastError());
     CP_HIP(hipMemcpyAsync(spl_out, d_out, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
@@ -163,5 +257,19 @@ extern "C" int32_t cp_partition_bisect_cost(cp_csr_t A, int64_t K, const cp_mode
         if (rc != CP_OK) return rc;
         if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, lf, hf, eps, flip, spl_out);
         return run_bisect<double>(A, K, model, lf, hf, eps, flip, spl_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+// partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f))  BisectIndexBottleneckSplitter.jl:5-166
+extern "C" int32_t cp_partition_bisect_index(cp_csr_t A, int64_t K, const cp_model_t *model, int32_t flip, int64_t *spl_out)
+{
+    try {
+        CP_REQUIRE(A && model && spl_out && K >= 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        int64_t li, hi; double lf, hf;
+        int32_t rc = cp_bound_stripe(A, K, model, &li, &hi, &lf, &hf);        // (c_lo, c_hi) = bound_stripe(...) ./ 1  (:39)
+        if (rc != CP_OK) return rc;
+        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, lf, hf, 0.0, flip, spl_out, true);
+        return run_bisect<double>(A, K, model, lf, hf, 0.0, flip, spl_out, true);
     } catch (const HipFail &e) { return e.code; }
 }

@@ -551,6 +551,32 @@ int32_t cp_bound_stripe(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t 
             }
             return CP_OK;
         }
+        if (model->kind == CP_MODEL_CONNECTIVITY && model->alpha_k && model->n_alpha_k > 0) {
+            // per-part alpha = the reference tests' FunkyConnectivityModel; its bound_stripe (test_Partitioners.jl:36-41) is
+            // (minimum, maximum) of (minimum(alpha), maximum(alpha), maximum_k ocl(1, n+1, k))
+            CP_REQUIRE(model->n_alpha_k >= K, CP_EINVAL, "bound_stripe: fewer per-part alphas than parts");
+            std::vector<int64_t> one((size_t)K, 1), np1((size_t)K, n + 1), ks((size_t)K);
+            for (int64_t k = 0; k < K; k++) ks[(size_t)k] = k + 1;
+            if (model->dtype == CP_I64) {
+                std::vector<int64_t> v((size_t)K);
+                int32_t rc = cp_oracle_eval(A, model, nullptr, CP_HINT_STEP, K, one.data(), np1.data(), ks.data(), v.data(), nullptr);
+                if (rc != CP_OK) return rc;
+                const int64_t *al = (const int64_t *)model->alpha_k;
+                int64_t amin = al[0], amax = al[0], fmax = v[0];
+                for (int64_t k = 1; k < K; k++) { amin = std::min(amin, al[k]); amax = std::max(amax, al[k]); fmax = std::max(fmax, v[(size_t)k]); }
+                *lo_i64 = std::min(amin, std::min(amax, fmax)); *hi_i64 = std::max(amin, std::max(amax, fmax));
+                *lo_f64 = (double)*lo_i64; *hi_f64 = (double)*hi_i64;
+            } else {
+                std::vector<double> v((size_t)K);
+                int32_t rc = cp_oracle_eval(A, model, nullptr, CP_HINT_STEP, K, one.data(), np1.data(), ks.data(), nullptr, v.data());
+                if (rc != CP_OK) return rc;
+                const double *al = (const double *)model->alpha_k;
+                double amin = al[0], amax = al[0], fmax = v[0];
+                for (int64_t k = 1; k < K; k++) { amin = std::min(amin, al[k]); amax = std::max(amax, al[k]); fmax = std::max(fmax, v[(size_t)k]); }
+                *lo_f64 = std::min(amin, std::min(amax, fmax)); *hi_f64 = std::max(amin, std::max(amax, fmax));
+            }
+            return CP_OK;
+        }
         if (model->kind == CP_MODEL_CONNECTIVITY) {                                    // ConnectivityCosts.jl:25-35
             int64_t one = 1, np1 = n + 1;
             if (model->dtype == CP_I64) {

@@ -324,6 +324,26 @@ class FlipBisectCostBottleneckSplitter(BisectCostBottleneckSplitter):
     flip = 1
 
 
+class BisectIndexBottleneckSplitter:
+    """BisectIndexBottleneckSplitter.jl:1-83 (exact bottleneck by bisection over split indices)"""
+    flip = 0
+
+    def __init__(self, f):
+        self.f = f
+
+
+class FlipBisectIndexBottleneckSplitter(BisectIndexBottleneckSplitter):
+    """BisectIndexBottleneckSplitter.jl:85-166"""
+    flip = 1
+
+
+class LazyBisectCostBottleneckSplitter:
+    """LazyBisectCostBottleneckSplitter.jl:1-4, connectivity specialisation :140-258"""
+
+    def __init__(self, f, eps):
+        self.f, self.eps = f, float(eps)
+
+
 class ConvexTotalChunker(_FMethod):
     pass
 

@@ -91,6 +91,15 @@ int32_t cp_pack_dynamic(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_
 /* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))  BisectCostBottleneckSplitter.jl:6-127 */
 int32_t cp_partition_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
                                  int32_t flip, int64_t *spl_out /* K+1 */);
+/* partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f))  BisectIndexBottleneckSplitter.jl:5-83, :85-166
+ * (exact bottleneck: bisection over the split index of every part in turn) */
+int32_t cp_partition_bisect_index(cp_csr_t csr, int64_t K, const cp_model_t *model, int32_t flip,
+                                  int64_t *spl_out /* K+1 */);
+/* partition_stripe(A, K, LazyBisectCostBottleneckSplitter(f::AbstractConnectivityModel, eps))
+ * LazyBisectCostBottleneckSplitter.jl:140-258 (forward-scan probes over the link array).
+ * Models that are not connectivity models return CP_EINVAL (the reference's generic method asserts, :486-501). */
+int32_t cp_partition_lazy_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
+                                      int64_t *spl_out /* K+1 */);
 /* pack_stripe(A, ConvexTotalChunker(..), [Pi]) / partition_stripe(A, K, ConvexTotalSplitter(..), [Pi])
  * ConvexTotalChunker.jl:9-265 */
 int32_t cp_pack_convex(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi,

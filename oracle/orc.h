@@ -99,6 +99,17 @@ int32_t orc_partition_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t
                                   int64_t K, const cp_model_t *mdl, double eps, int32_t flip,
                                   int64_t *spl_out, int64_t *n_probes_out);
 
+/* partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f)) BisectIndexBottleneckSplitter.jl:5-166 */
+int32_t orc_partition_bisect_index(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                   int64_t K, const cp_model_t *mdl, int32_t flip,
+                                   int64_t *spl_out, int64_t *n_probes_out);
+
+/* partition_stripe(A, K, LazyBisectCostBottleneckSplitter(f::AbstractConnectivityModel, eps))
+ * LazyBisectCostBottleneckSplitter.jl:140-258 */
+int32_t orc_partition_lazy_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                       int64_t K, const cp_model_t *mdl, double eps,
+                                       int64_t *spl_out, int64_t *n_probes_out);
+
 /* pack_stripe(A, ConvexTotalChunker(...)) / partition_stripe(A, K, ConvexTotalSplitter(...))
  * ConvexTotalChunker.jl:9-265 */
 int32_t orc_pack_convex(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,

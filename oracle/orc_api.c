@@ -32,7 +32,12 @@
                                    double, int64_t *, int64_t *);                                          \
     int32_t orc_api_partition_convex##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,       \
                                         int64_t, const cp_model_t *, const cp_rowpart_t *,                 \
-                                        const cp_model_t *, int64_t, double, int64_t *);
+                                        const cp_model_t *, int64_t, double, int64_t *);               \
+    int32_t orc_api_partition_bisect_index##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, \
+                                              int64_t, const cp_model_t *, int32_t, int64_t *, int64_t *); \
+    int32_t orc_api_partition_lazy_bisect_cost##S(int64_t, int64_t, int64_t, const int64_t *,              \
+                                                  const int64_t *, int64_t, const cp_model_t *, double,    \
+                                                  int64_t *, int64_t *);
 DECL(int64_t, _i64)
 DECL(double, _f64)
 
@@ -116,6 +121,20 @@ int32_t orc_partition_convex(int64_t m, int64_t n, int64_t N, const int64_t *pos
 {
     return IS_I(mdl) ? orc_api_partition_convex_i64(m, n, N, pos, idx, K, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out)
                      : orc_api_partition_convex_f64(m, n, N, pos, idx, K, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out);
+}
+
+int32_t orc_partition_bisect_index(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                   int64_t K, const cp_model_t *mdl, int32_t flip, int64_t *spl_out, int64_t *n_probes_out)
+{
+    return IS_I(mdl) ? orc_api_partition_bisect_index_i64(m, n, N, pos, idx, K, mdl, flip, spl_out, n_probes_out)
+                     : orc_api_partition_bisect_index_f64(m, n, N, pos, idx, K, mdl, flip, spl_out, n_probes_out);
+}
+
+int32_t orc_partition_lazy_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                       int64_t K, const cp_model_t *mdl, double eps, int64_t *spl_out, int64_t *n_probes_out)
+{
+    return IS_I(mdl) ? orc_api_partition_lazy_bisect_cost_i64(m, n, N, pos, idx, K, mdl, eps, spl_out, n_probes_out)
+                     : orc_api_partition_lazy_bisect_cost_f64(m, n, N, pos, idx, K, mdl, eps, spl_out, n_probes_out);
 }
 
 /* EquiPartitioner.jl:7 : spl[k] = (k-1)*fld(n,K) + min(n % K, k-1) + 1, k = 1..K+1 */

@@ -62,6 +62,18 @@ class OracleBackend:
         return lib().orc_pack_dynamic(*self._A(A), mm.ptr, C.byref(rp) if rp is not None else None,
                                       wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
 
+    def partition_bisect_index(self, A, K, mm, flip, spl):
+        pr = np.zeros(1, dtype=np.int64)
+        rc = lib().orc_partition_bisect_index(*self._A(A), _i64(K), mm.ptr, C.c_int32(flip), _p(spl), _p(pr))
+        self.last_probes = int(pr[0])
+        return rc
+
+    def partition_lazy_bisect_cost(self, A, K, mm, eps, spl):
+        pr = np.zeros(1, dtype=np.int64)
+        rc = lib().orc_partition_lazy_bisect_cost(*self._A(A), _i64(K), mm.ptr, C.c_double(eps), _p(spl), _p(pr))
+        self.last_probes = int(pr[0])
+        return rc
+
     def partition_bisect_cost(self, A, K, mm, eps, flip, spl, probes=None):
         pr = np.zeros(1, dtype=np.int64)
         rc = lib().orc_partition_bisect_cost(*self._A(A), _i64(K), mm.ptr, C.c_double(eps), C.c_int32(flip),

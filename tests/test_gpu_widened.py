@@ -1,0 +1,72 @@
+"""GPU parity for the SURVEY 8(f) rows: [Flip]BisectIndexBottleneckSplitter and LazyBisectCostBottleneckSplitter
+(connectivity specialisation) through the C ABI vs the CPU oracle: bit-exact split vectors."""
+import numpy as np
+import pytest
+
+from util import cp, sprand, golden_matrices, suitesparse_shaped, banded
+
+pytestmark = pytest.mark.gpu
+
+
+def _mats(seed):
+    rng = np.random.default_rng(seed)
+    mats = [sprand(m, n, 0.3, rng) for m in (1, 3, 8) for n in (1, 2, 3, 8, 40)] + list(golden_matrices().values())
+    return mats
+
+
+def test_bisect_index_matches_oracle(hip, orc):
+    rng = np.random.default_rng(3)
+    for A in _mats(31) + [suitesparse_shaped(20000, 8, 6)]:
+        for K in (1, 2, 3, 8, 32):
+            if A.n > 5000 and K > 8:
+                continue
+            for f in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineConnectivityModel(0, 3, 1, 3),
+                      cp.AffineConnectivityModel(0.5, 0.25, 1.0, 3.0), cp.AffineWorkModel(2.5, 0.5, 1.25),
+                      cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=rng.integers(1, 11, K).tolist())):
+                for meth in (cp.BisectIndexBottleneckSplitter(f), cp.FlipBisectIndexBottleneckSplitter(f)):
+                    got = cp.partition_stripe(A, K, meth, backend=hip)
+                    want = cp.partition_stripe(A, K, meth, backend=orc)
+                    assert got == want, (A, K, f.kind, f.dtype, meth.flip)
+            # decreasing costs for the Flip variant (test_Partitioners.jl:116-152)
+            base = 1 + A.nnz + 3 * A.n + 3 * A.m
+            f = cp.AffineConnectivityModel(0, -3, -1, -3, alpha_k=(base + rng.integers(1, 11, K)).tolist())
+            got = cp.partition_stripe(A, K, cp.FlipBisectIndexBottleneckSplitter(f), backend=hip)
+            want = cp.partition_stripe(A, K, cp.FlipBisectIndexBottleneckSplitter(f), backend=orc)
+            assert got == want, (A, K, "flip funky")
+
+
+def test_bisect_index_is_optimal(hip):
+    """test_Partitioners.jl:101,112 with eps = 0: same bottleneck as the exact DP (computed on the device)."""
+    A = suitesparse_shaped(3000, 6, 2)
+    for f in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
+        for K in (2, 7):
+            opt = cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(f), backend=hip)
+            got = cp.partition_stripe(A, K, cp.BisectIndexBottleneckSplitter(f), backend=hip)
+            assert cp.bottleneck_value(A, got, f, backend=hip) == cp.bottleneck_value(A, opt, f, backend=hip)
+
+
+def test_lazy_bisect_cost_matches_oracle(hip, orc):
+    rng = np.random.default_rng(5)
+    big = [suitesparse_shaped(20000, 8, 6), suitesparse_shaped(60000, 3, 7), banded(30000, 16, 0.5, 8)]
+    # one very heavy column (longer than a 16 Ki-entry chunk) and runs of empty columns
+    n = 3000
+    deg = np.zeros(n, dtype=np.int64); deg[5] = 40000; deg[100:200] = 7; deg[2500:] = 3
+    colptr = np.concatenate([[1], 1 + np.cumsum(deg)]).astype(np.int64)
+    rows = np.concatenate([np.sort(rng.choice(50000, size=d, replace=False)) + 1 for d in deg if d > 0]).astype(np.int64)
+    big.append(cp.SparseMatrixCSC(50000, n, colptr, rows))
+    for A in _mats(32) + big:
+        for K in (1, 2, 3, 8, 32):
+            for f in (cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineConnectivityModel(0, 0, 0, 1),
+                      cp.AffineConnectivityModel(0.5, 0.25, 1.0, 3.0),
+                      cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=rng.integers(1, 11, K).tolist())):
+                for eps in (0.1, 0.01, 0.001):
+                    meth = cp.LazyBisectCostBottleneckSplitter(f, eps)
+                    got = cp.partition_stripe(A, K, meth, backend=hip)
+                    want = cp.partition_stripe(A, K, meth, backend=orc)
+                    assert got == want, (A, K, f.dtype, eps)
+
+
+def test_lazy_rejects_work_models(hip):
+    A = suitesparse_shaped(100, 4, 1)
+    with pytest.raises(AssertionError):
+        cp.partition_stripe(A, 2, cp.LazyBisectCostBottleneckSplitter(cp.AffineWorkModel(0, 10, 1), 0.1), backend=hip)

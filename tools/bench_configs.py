@@ -57,7 +57,27 @@ def main():
         rc, obj = hip.objective(h, K, spl, mm, None, 1)
         out["cfg2_bisect_" + name] = {"n": n, "nnz": int(rowval.numel()), "K": K, "eps": 0.01, "seconds": t, "bottleneck": obj,
                                       "spl_ok": bool(spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0))}
+        if name == "connectivity":                      # SURVEY 8(f) rows on the same input
+            spl2 = np.zeros(K + 1, dtype=np.int64)
+            def run_lazy():
+                hip.reset_cache(h)
+                rc = hip.partition_lazy_bisect_cost(h, K, mm, 0.01, spl2)
+                assert rc == 0, hip.last_error()
+            t = timeit(run_lazy)
+            rc, obj2 = hip.objective(h, K, spl2, mm, None, 1)
+            out["cfg2_lazy_bisect_connectivity"] = {"seconds": t, "bottleneck": obj2, "same_split_as_bisect_cost": bool(np.array_equal(spl, spl2))}
+        spl3 = np.zeros(K + 1, dtype=np.int64)
+        def run_index():
+            hip.reset_cache(h)
+            rc = hip.partition_bisect_index(h, K, mm, 0, spl3)
+            assert rc == 0, hip.last_error()
+        t = timeit(run_index, reps=1)
+        rc, obj3 = hip.objective(h, K, spl3, mm, None, 1)
+        out["cfg2_bisect_index_" + name] = {"seconds": t, "bottleneck": obj3}
     hip.csr_destroy(h)
+    if args.n4 <= 0:
+        print(json.dumps(out))
+        return
     # ---- config 4
     n = args.n4
     colptr, rowval = banded_dev(n, 16, 0.5, 0xDEADBEEF + 4, dev)
