@@ -6,7 +6,8 @@ hand-written HIP kernels behind the C ABI of include/chainpart.h (csrc/).
 """
 from .types import *          # noqa: F401,F403
 from .types import to_map, to_domain   # noqa: F401
-from .models import (AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCutModel,      # noqa: F401
+from .models import (PowerWorkModel, ConvexWorkModel, ConcaveWorkModel,   # noqa: F401
+                     AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCutModel,      # noqa: F401
                      ColumnBlockComponentCostModel, BlockComponentCostModel, VertexCount, FeasibleCost,
                      ConstrainedCost, EquiSplitter, EquiChunker, DynamicTotalSplitter,
                      DynamicBottleneckSplitter, DynamicTotalChunker, DynamicBottleneckChunker,
@@ -14,7 +15,7 @@ from .models import (AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCu
                      BisectCostBottleneckSplitter, FlipBisectCostBottleneckSplitter,
                      BisectIndexBottleneckSplitter, FlipBisectIndexBottleneckSplitter,
                      LazyBisectCostBottleneckSplitter,
-                     ConvexTotalChunker, ConvexTotalSplitter)
+                     ConvexTotalChunker, ConvexTotalSplitter, ConcaveTotalChunker, ConcaveTotalSplitter)
 from . import _lib  # noqa: F401
 from .api import (partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
                   bottleneck_value, netcount, selfnetcount, dominancecount, set_default_backend,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
-    "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost",
+    "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
 ]
 
 _lib = None
@@ -136,6 +136,14 @@ class HipBackend:
     def partition_convex(self, A, K, mm, rp, wm, wi, wf, spl):
         return self.lib.cp_partition_convex(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
                                             wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
+
+    def pack_concave(self, A, mm, rp, wm, wi, wf, spl, Kout):
+        return self.lib.cp_pack_concave(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,
+                                        wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
+
+    def partition_concave(self, A, K, mm, rp, wm, wi, wf, spl):
+        return self.lib.cp_partition_concave(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
+                                             wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
 
     # ---- oracles / scoring
     def oracle_eval(self, A, mm, rp, hint, j, jp, k, out):

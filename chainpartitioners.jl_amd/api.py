@@ -155,6 +155,12 @@ def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) ->
         rc = b.partition_convex(A, K, mm, rp, wm, wi, wf, spl)
         _check(rc, "partition_stripe(ConvexTotalSplitter)", b)
         return SplitPartition(K, spl)
+    if isinstance(method, M.ConcaveTotalSplitter):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = b.partition_concave(A, K, mm, rp, wm, wi, wf, spl)
+        _check(rc, "partition_stripe(ConcaveTotalSplitter)", b)
+        return SplitPartition(K, spl)
     raise NotImplementedError(f"partition_stripe: method {type(method).__name__} is outside the hot path")
 
 
@@ -178,6 +184,13 @@ def pack_stripe(A: SparseMatrixCSC, method, Pi=None, *, backend=None) -> SplitPa
         Kout = np.zeros(1, dtype=np.int64)
         rc = b.pack_convex(A, mm, rp, wm, wi, wf, spl, Kout)
         _check(rc, "pack_stripe(ConvexTotalChunker)", b)
+        return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
+    if isinstance(method, M.ConcaveTotalChunker):
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        spl = np.zeros(A.n + 1, dtype=np.int64)
+        Kout = np.zeros(1, dtype=np.int64)
+        rc = b.pack_concave(A, mm, rp, wm, wi, wf, spl, Kout)
+        _check(rc, "pack_stripe(ConcaveTotalChunker)", b)
         return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
     raise NotImplementedError(f"pack_stripe: method {type(method).__name__} is outside the hot path")
 

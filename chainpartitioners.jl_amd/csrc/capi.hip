@@ -97,7 +97,9 @@ static int32_t guarded(F &&f)
 
 static bool model_known(const cp_model_t *m)
 {
-    return m && m->kind >= CP_MODEL_FEASIBLE && m->kind <= CP_MODEL_VERTEX_COUNT && (m->dtype == CP_I64 || m->dtype == CP_F64);
+    if (!m || m->kind < CP_MODEL_FEASIBLE || m->kind > CP_MODEL_POWER_WORK) return false;
+    if (m->kind == CP_MODEL_POWER_WORK) return m->dtype == CP_F64;
+    return m->dtype == CP_I64 || m->dtype == CP_F64;
 }
 
 static bool all_integral(const cp_model_t *m)
@@ -467,7 +469,7 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
             return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         }
         CP_REQUIRE(model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT ||
-                       model->kind == CP_MODEL_COLBLOCK,
+                       model->kind == CP_MODEL_COLBLOCK || model->kind == CP_MODEL_POWER_WORK,
                    CP_EUNSUPPORTED, "model kind has no device DP path yet");
         if (model->dtype == CP_I64) return run_dynamic<int64_t>(A, K, combine, order, model, spl_out, nullptr, nullptr);
         return run_dynamic<double>(A, K, combine, order, model, spl_out, nullptr, nullptr);

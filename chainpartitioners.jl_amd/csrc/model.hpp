@@ -60,6 +60,15 @@ __device__ __forceinline__ TC dm_comp(int32_t is_const, TC c, const TC *tab, int
     return tab[w];
 }
 
+// alpha + (nv*b_vertex + np*b_pin)^gamma  (test_Partitioners.jl:60,70); Float64 models only
+__device__ __forceinline__ double pw_apply(double alpha, const double *p, int64_t nv, int64_t np)
+{
+    double x = (double)nv * p[CP_P_VERTEX] + (double)np * p[CP_P_PIN];
+    double g = p[CP_P_GAMMA];
+    return alpha + (g == 2.0 ? x * x : pow(x, g));
+}
+__device__ __forceinline__ int64_t pw_apply(int64_t, const int64_t *, int64_t, int64_t) { return 0; }
+
 // model applied to counts; alpha is resolved by the caller (per-part alpha[k] or scalar)
 template <typename TC>
 __device__ __forceinline__ TC dm_apply(const DevModel<TC> &m, TC alpha, int64_t nv, int64_t np, int64_t nn, int64_t nl)
@@ -77,6 +86,8 @@ __device__ __forceinline__ TC dm_apply(const DevModel<TC> &m, TC alpha, int64_t 
                     cmulc(nn, dm_comp(m.bc_const[0], m.bc_c[0], m.bc_tab[0], m.bc_len[0], nv)));
     case CP_MODEL_VERTEX_COUNT:
         return (TC)nv;
+    case CP_MODEL_POWER_WORK:
+        return pw_apply(alpha, m.p, nv, np);
     default:
         return (TC)0;
     }

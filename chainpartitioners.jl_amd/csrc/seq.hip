@@ -214,6 +214,7 @@ struct Cvx {
     int64_t k;
     const Ext<TC> *base; int64_t blo, bhi;       // base[j] valid for j in [blo,bhi] (1-based index into base)
     const Cvx<TC> *inner; const int64_t *sig_j, *sig_jp; int64_t I;
+    const SeqWeight *w;        // non-null: f is a ConstrainedCostOracle (Costs.jl:140-146): infinity where w(j,j') > w_max
 };
 
 template <typename TC>
@@ -223,6 +224,7 @@ __device__ Ext<TC> cvx_eval(const SeqOracle<TC> &O, const Cvx<TC> &F, int64_t j,
         Ext<TC> b = (G.blo <= j && j <= G.bhi) ? G.base[j] : ext_inf<TC>();
         return ext_add(b, ext_of(ocl(O, j, jp, G.k))); }
     Ext<TC> b = (F.blo <= j && j <= F.bhi) ? F.base[j] : ext_inf<TC>();
+    if (F.w && wgt_gt(*F.w, j, jp)) return ext_add(b, ext_inf<TC>());
     return ext_add(b, ext_of(ocl(O, j, jp, F.k)));
 }
 
@@ -289,7 +291,7 @@ __device__ int32_t chunk_convex_constrained(const SeqOracle<TC> &O, const CView<
         I += 1;
         if (I == 2) return CP_EINVAL;          // a single column exceeds w_max (the reference indexes sigma_j'[0])
         for (int64_t i = 2; i <= I - 1; i++) sig_cst[i] = ext_inf<TC>();
-        Cvx<TC> G; G.mode = 3; G.k = 0; G.base = nullptr; G.blo = 0; G.bhi = -1; G.inner = &F; G.sig_j = sig_j; G.sig_jp = sig_jp; G.I = I;
+        Cvx<TC> G; G.mode = 3; G.k = 0; G.base = nullptr; G.blo = 0; G.bhi = -1; G.inner = &F; G.sig_j = sig_j; G.sig_jp = sig_jp; G.I = I; G.w = nullptr;
         CView<TC> SV; SV.cst = sig_cst; SV.ptr = sig_ptr; SV.lo = 1; SV.hi = I - 1;
         chunk_convex(O, SV, G, (int64_t)1, I - 1, ftr);
         for (int64_t ip = 2; ip <= I - 1; ip++) cv_set(V, A1(sig_jp, I - ip), sig_cst[ip], A1(sig_j, I - sig_ptr[ip]));
@@ -308,13 +310,80 @@ __global__ void __launch_bounds__(64) k_pack_convex(SeqOracle<TC> O, SeqWeight W
     int64_t n = O.n;
     for (int64_t t = 0; t <= n + 1; t++) { cst[t] = ext_inf<TC>(); ptr[t] = 0; }
     cst[1] = ext_of((TC)0);
-    Cvx<TC> F; F.mode = 0; F.k = 0; F.base = cst; F.blo = 1; F.bhi = n + 1; F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0;
+    Cvx<TC> F; F.mode = 0; F.k = 0; F.base = cst; F.blo = 1; F.bhi = n + 1; F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0; F.w = nullptr;
     CView<TC> V; V.cst = cst; V.ptr = ptr; V.lo = 1; V.hi = n + 1;
     int32_t rc = CP_OK;
     if (!constrained) chunk_convex(O, V, F, (int64_t)1, n + 1, ftr);
     else if (n >= 1) rc = chunk_convex_constrained(O, V, F, W, (int64_t)1, n + 1, ftr, sig_j, sig_jp, sig_ptr, sig_cst);
     if (threadIdx.x == 0) *status = rc;
 }
+
+// ------------------------------------------------------------------ ConcaveTotalChunker.jl
+// chunk_concave!(cst, ptr, f, j0, j'1, ftr)  :57-114 ; ftr = CircularDeque of (j, h) pairs in dq[2*cap]
+template <typename TC>
+__device__ int32_t chunk_concave(const SeqOracle<TC> &O, const CView<TC> &V, const Cvx<TC> &F, int64_t j0, int64_t jp1, int64_t *dq, int64_t cap)
+{
+    int64_t head = 0, len = 0;
+#define DQ_SLOT(i) (((head + (i)) % cap) * 2)
+#define DQ_PUSH(a, b) do { int64_t s_ = DQ_SLOT(len); dq[s_] = (a); dq[s_ + 1] = (b); len++; } while (0)
+    DQ_PUSH(j0, j0 + 1);
+    for (int64_t jp = j0 + 1; jp <= jp1; jp++) {
+        int64_t s0 = DQ_SLOT(0);
+        int64_t j = dq[s0], h = dq[s0 + 1];
+        Ext<TC> c = cvx_eval(O, F, j, jp);
+        Ext<TC> c2 = cvx_eval(O, F, jp - 1, jp);
+        if (ext_le(c2, c)) {
+            if (ext_le(c2, cv_get(V, jp))) cv_set(V, jp, c2, jp - 1);
+            head = 0; len = 0;
+            DQ_PUSH(jp - 1, jp + 1);
+        } else {
+            if (ext_le(c, cv_get(V, jp))) cv_set(V, jp, c, j);
+            for (;;) {                                                // :76-78
+                if (len == 0) return CP_EINVAL;                       // the reference would throw on an empty deque
+                int64_t sl = DQ_SLOT(len - 1);
+                j = dq[sl]; h = dq[sl + 1];
+                if (ext_le(cvx_eval(O, F, jp - 1, h), cvx_eval(O, F, j, h))) len--; else break;
+            }
+            int64_t h_lo = h + 1, h_hi = jp1;                         // :89-99
+            while (h_lo <= h_hi) {
+                h = (int64_t)(((uint64_t)(h_lo + h_hi)) >> 1);
+                if (ext_lt(cvx_eval(O, F, j, h), cvx_eval(O, F, jp - 1, h))) h_lo = h + 1; else h_hi = h - 1;
+            }
+            h = h_lo;
+            if (h != jp1 + 1) DQ_PUSH(jp - 1, h);
+            s0 = DQ_SLOT(0);
+            j = dq[s0];
+            head = (head + 1) % cap; len--;                           // popfirst!
+            if (len == 0 || dq[DQ_SLOT(0) + 1] != jp + 1) {           // pushfirst!(ftr, (j, j' + 1))
+                head = (head + cap - 1) % cap;
+                dq[2 * head] = j; dq[2 * head + 1] = jp + 1; len++;
+            }
+        }
+    }
+#undef DQ_SLOT
+#undef DQ_PUSH
+    return CP_OK;
+}
+
+// pack_stripe(A, ConcaveTotalChunker(f | ConstrainedCost))  :9-24
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_concave(SeqOracle<TC> O, SeqWeight W, int constrained, Ext<TC> *cst, int64_t *ptr, int64_t *dq,
+                                                     int32_t *status)
+{
+    int64_t n = O.n;
+    for (int64_t t = 0; t <= n + 1; t++) { cst[t] = ext_inf<TC>(); ptr[t] = 0; }
+    cst[1] = ext_of((TC)0);
+    Cvx<TC> F; F.mode = 0; F.k = 0; F.base = cst; F.blo = 1; F.bhi = n + 1; F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0;
+    F.w = constrained ? &W : nullptr;
+    CView<TC> V; V.cst = cst; V.ptr = ptr; V.lo = 1; V.hi = n + 1;
+    int32_t rc = chunk_concave(O, V, F, (int64_t)1, n + 1, dq, n + 1);
+    if (threadIdx.x == 0) *status = rc;
+}
+
+// partition_stripe(A, K, ConcaveTotalSplitter(..))  :26-55, :140-180.  cst/ptr: K layers of (n+2) slots.
+template <typename TC>
+__global__ void __launch_bounds__(64) k_partition_concave(SeqOracle<TC> O, SeqWeight W, int constrained, int64_t K, Ext<TC> *cst, int64_t *ptr,
+                                                          int64_t *jlo, int64_t *jhi, int64_t *dq, int64_t *spl, int32_t *status);
 
 // column_constraints  DynamicSplitter.jl:144-172
 __device__ void column_constraints(int64_t n, int64_t K, const SeqWeight &W, int64_t *jlo, int64_t *jhi)
@@ -378,11 +447,48 @@ __global__ void __launch_bounds__(64) k_partition_convex(SeqOracle<TC> O, SeqWei
     int32_t rc = CP_OK;
     for (int64_t k = 2; k <= K && rc == CP_OK; k++) {
         Cvx<TC> F; F.mode = 0; F.k = k; F.base = cst + (k - 2) * ld; F.blo = A1(jlo, k - 1); F.bhi = A1(jhi, k - 1);
-        F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0;
+        F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0; F.w = nullptr;
         CView<TC> V; V.cst = cst + (k - 1) * ld; V.ptr = ptr + (k - 1) * ld; V.lo = A1(jlo, k); V.hi = A1(jhi, k);
         for (int64_t jp = A1(jlo, k); jp <= A1(jhi, k); jp++) cv_set(V, jp, cvx_eval(O, F, jp, jp), jp);
         if (!constrained) chunk_convex(O, V, F, (int64_t)1, n + 1, ftr);
         else rc = chunk_convex_constrained(O, V, F, W, A1(jlo, k - 1), A1(jhi, k), ftr, sig_j, sig_jp, sig_ptr, sig_cst);
+    }
+    if (rc == CP_OK) {
+        A1(spl, K + 1) = n + 1;
+        for (int64_t k = K; k >= 1; k--) {
+            int64_t jp = A1(spl, k + 1);
+            A1(spl, k) = (A1(jlo, k) <= jp && jp <= A1(jhi, k)) ? ptr[(k - 1) * ld + jp] : 0;
+        }
+    }
+    if (threadIdx.x == 0) *status = rc;
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_partition_concave(SeqOracle<TC> O, SeqWeight W, int constrained, int64_t K, Ext<TC> *cst, int64_t *ptr,
+                                                          int64_t *jlo, int64_t *jhi, int64_t *dq, int64_t *spl, int32_t *status)
+{
+    int64_t n = O.n, ld = n + 2;
+    if (constrained) {
+        column_constraints(n, K, W, jlo, jhi);                         // :150
+        if (A1(jhi, K) < n + 1) {                                      // :152-157
+            for (int64_t k = 1; k <= K + 1; k++) A1(spl, k) = 1;
+            A1(spl, K + 1) = n + 1;
+            if (threadIdx.x == 0) *status = CP_INFEASIBLE;
+            return;
+        }
+    } else {
+        for (int64_t k = 1; k <= K; k++) { A1(jlo, k) = 1; A1(jhi, k) = n + 1; }
+    }
+    for (int64_t t = 0; t < ld * K; t++) { cst[t] = ext_inf<TC>(); ptr[t] = 0; }
+    for (int64_t jp = A1(jlo, 1); jp <= A1(jhi, 1); jp++) { cst[jp] = ext_of(ocl(O, 1, jp, 1)); ptr[jp] = 1; }
+    int32_t rc = CP_OK;
+    for (int64_t k = 2; k <= K && rc == CP_OK; k++) {
+        Cvx<TC> F; F.mode = 0; F.k = k; F.base = cst + (k - 2) * ld; F.blo = A1(jlo, k - 1); F.bhi = A1(jhi, k - 1);
+        F.inner = nullptr; F.sig_j = nullptr; F.sig_jp = nullptr; F.I = 0; F.w = nullptr;
+        CView<TC> V; V.cst = cst + (k - 1) * ld; V.ptr = ptr + (k - 1) * ld; V.lo = A1(jlo, k); V.hi = A1(jhi, k);
+        for (int64_t jp = A1(jlo, k); jp <= A1(jhi, k); jp++) cv_set(V, jp, cvx_eval(O, F, jp, jp), jp);
+        if (!constrained) rc = chunk_concave(O, V, F, (int64_t)1, n + 1, dq, n + 1);
+        else rc = chunk_concave(O, V, F, A1(jlo, k - 1), A1(jhi, k), dq, n + 1);                       // :176
     }
     if (rc == CP_OK) {
         A1(spl, K + 1) = n + 1;
@@ -681,6 +787,71 @@ int32_t run_partition_convex(cp_csr_s *A, int64_t K, const cp_model_t *mdl, cons
 }
 
 template <typename TC>
+int32_t run_pack_concave(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi, double wf,
+                         int64_t *spl_out, int64_t *K_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    SeqWeight W = make_weight(A, w, wi, wf);
+    int constrained = W.kind != CP_MODEL_FEASIBLE;
+    DBuf<Ext<TC>> cst((size_t)n + 2);
+    DBuf<int64_t> ptr((size_t)n + 2), dq((size_t)(2 * (n + 2)));
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_concave<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, cst.p, ptr.p, dq.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    std::vector<int64_t> h((size_t)n + 2);
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(h.data(), ptr.p, sizeof(int64_t) * (size_t)(n + 2), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc != CP_OK) { set_error("ConcaveTotalChunker: the candidate deque ran empty (the reference throws)"); return rc; }
+    std::vector<int64_t> sp((size_t)n + 1);
+    for (int64_t jp = 1; jp <= n + 1; jp++) sp[(size_t)jp - 1] = h[(size_t)jp];
+    int64_t K = unravel_chunks_host(sp, n);
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = sp[(size_t)k];
+    *K_out = K;
+    return CP_OK;
+}
+
+template <typename TC>
+int32_t run_partition_concave(cp_csr_s *A, int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi,
+                              double wf, int64_t *spl_out)
+{
+    hipStream_t s = A->stream;
+    int64_t n = A->n;
+    SeqWeight W = make_weight(A, w, wi, wf);
+    int constrained = W.kind != CP_MODEL_FEASIBLE;
+    if (!constrained && K == 1) { spl_out[0] = 1; spl_out[1] = n + 1; return CP_OK; }         // :32-34
+    CP_REQUIRE((double)K * (double)(n + 2) < 4e8, CP_EUNSUPPORTED, "ConcaveTotalSplitter tables exceed the device budget");
+    std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
+    seq_oracle<TC>(A, mdl, Pi, *C);
+    DBuf<Ext<TC>> cst((size_t)K * (size_t)(n + 2));
+    DBuf<int64_t> ptr((size_t)K * (size_t)(n + 2)), jlo((size_t)K), jhi((size_t)K), dq((size_t)(2 * (n + 2))), spl((size_t)K + 1);
+    DBuf<int32_t> st(1);
+    CP_HIP(hipMemsetAsync(st.p, 0, sizeof(int32_t), s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition_concave<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, K, cst.p, ptr.p, jlo.p,
+                           jhi.p, dq.p, spl.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    int32_t rc = 0;
+    CP_HIP(hipMemcpyAsync(&rc, st.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(spl_out, spl.p, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    if (rc == CP_EINVAL) set_error("ConcaveTotalSplitter: the candidate deque ran empty (the reference throws)");
+    return rc;
+}
+
+template <typename TC>
 int32_t run_dyn_constrained(cp_csr_s *A, int64_t K, int32_t g, int32_t order, const cp_model_t *mdl, const cp_rowpart_t *Pi,
                             const cp_model_t *w, int64_t wi, double wf, int64_t *spl_out)
 {
@@ -756,7 +927,8 @@ using namespace cpk;
 static bool seq_model_ok(const cp_model_t *m)
 {
     return m && (m->kind == CP_MODEL_WORK || m->kind == CP_MODEL_CONNECTIVITY || m->kind == CP_MODEL_HYPEREDGE_CUT ||
-                 m->kind == CP_MODEL_COLBLOCK || m->kind == CP_MODEL_BLOCK) && (m->dtype == CP_I64 || m->dtype == CP_F64);
+                 m->kind == CP_MODEL_COLBLOCK || m->kind == CP_MODEL_BLOCK || (m->kind == CP_MODEL_POWER_WORK && m->dtype == CP_F64)) &&
+           (m->dtype == CP_I64 || m->dtype == CP_F64);
 }
 
 extern "C" {
@@ -791,6 +963,28 @@ int32_t cp_partition_convex(cp_csr_t A, int64_t K, const cp_model_t *model, cons
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_partition_convex<int64_t>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         return run_partition_convex<double>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+int32_t cp_pack_concave(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64,
+                        double wmax_f64, int64_t *spl_out, int64_t *K_out)
+{
+    try {
+        CP_REQUIRE(A && spl_out && K_out && seq_model_ok(model) && weight_ok(weight), CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_pack_concave<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+        return run_pack_concave<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+    } catch (const HipFail &e) { return e.code; }
+}
+
+int32_t cp_partition_concave(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight,
+                             int64_t wmax_i64, double wmax_f64, int64_t *spl_out)
+{
+    try {
+        CP_REQUIRE(A && spl_out && K >= 1 && seq_model_ok(model) && weight_ok(weight), CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(A->device));
+        if (model->dtype == CP_I64) return run_partition_concave<int64_t>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
+        return run_partition_concave<double>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
     } catch (const HipFail &e) { return e.code; }
 }
 

@@ -26,7 +26,7 @@ import numpy as np
 
 CP_I64, CP_F64 = 0, 1
 (CP_MODEL_FEASIBLE, CP_MODEL_WORK, CP_MODEL_CONNECTIVITY, CP_MODEL_HYPEREDGE_CUT,
- CP_MODEL_COLBLOCK, CP_MODEL_BLOCK, CP_MODEL_VERTEX_COUNT) = range(7)
+ CP_MODEL_COLBLOCK, CP_MODEL_BLOCK, CP_MODEL_VERTEX_COUNT, CP_MODEL_POWER_WORK) = range(8)
 CP_COMBINE_SUM, CP_COMBINE_MAX = 0, 1
 CP_ORDER_SPLITTER, CP_ORDER_CHUNKER = 0, 1
 CP_MAX_R = 4
@@ -130,6 +130,35 @@ class AffineWorkModel(_Model):
     def __call__(self, n_vertices, n_pins, k=None):
         a = self.alpha if self.alpha_k is None or k is None else self.alpha_k[k - 1]
         return a + n_vertices * self.beta_vertex + n_pins * self.beta_pin
+
+
+class PowerWorkModel(_Model):
+    """alpha + (n_vertices*beta_vertex + n_pins*beta_pin)^gamma, Float64: the ConvexWorkModel (gamma 0.8) and
+    ConcaveWorkModel (gamma 2) of the reference's tests (test/test_Partitioners.jl:54-74)."""
+    kind = CP_MODEL_POWER_WORK
+
+    def __init__(self, alpha, beta_vertex, beta_pin, gamma):
+        self.alpha, self.beta_vertex, self.beta_pin, self.gamma = float(alpha), float(beta_vertex), float(beta_pin), float(gamma)
+        self.alpha_k = None
+        self.dtype = CP_F64
+
+    def _params(self):
+        return [self.alpha, self.beta_vertex, self.beta_pin, self.gamma]
+
+    def _alpha_k(self):
+        return None
+
+    def __call__(self, n_vertices, n_pins, k=None):
+        x = n_vertices * self.beta_vertex + n_pins * self.beta_pin
+        return self.alpha + (x * x if self.gamma == 2.0 else x ** self.gamma)
+
+
+def ConvexWorkModel(alpha, beta_vertex, beta_pin):
+    return PowerWorkModel(alpha, beta_vertex, beta_pin, 0.8)
+
+
+def ConcaveWorkModel(alpha, beta_vertex, beta_pin):
+    return PowerWorkModel(alpha, beta_vertex, beta_pin, 2.0)
 
 
 class AffineConnectivityModel(_Model):
@@ -350,3 +379,11 @@ class ConvexTotalChunker(_FMethod):
 
 class ConvexTotalSplitter(_FMethod):
     pass
+
+
+class ConcaveTotalChunker(_FMethod):
+    """ConcaveTotalChunker.jl:1-24"""
+
+
+class ConcaveTotalSplitter(_FMethod):
+    """ConcaveTotalChunker.jl:5-55, :140-180"""

@@ -91,6 +91,15 @@ int32_t cp_pack_dynamic(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_
 /* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))  BisectCostBottleneckSplitter.jl:6-127 */
 int32_t cp_partition_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
                                  int32_t flip, int64_t *spl_out /* K+1 */);
+/* pack_stripe(A, ConcaveTotalChunker(f | ConstrainedCost(f,w,w_max)), [Pi]) ConcaveTotalChunker.jl:9-24, chunk_concave! :57-114;
+ * partition_stripe(A, K, ConcaveTotalSplitter(..), [Pi]) :26-55 and the ConstrainedCost method :140-180.
+ * The candidate-deque algorithm is exact for concave (Monge) costs, e.g. CP_MODEL_POWER_WORK with gamma >= 1. */
+int32_t cp_pack_concave(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi,
+                        const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                        int64_t *spl_out /* n+1 */, int64_t *K_out);
+int32_t cp_partition_concave(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi,
+                             const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                             int64_t *spl_out /* K+1 */);
 /* partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f))  BisectIndexBottleneckSplitter.jl:5-83, :85-166
  * (exact bottleneck: bisection over the split index of every part in turn) */
 int32_t cp_partition_bisect_index(cp_csr_t csr, int64_t K, const cp_model_t *model, int32_t flip,

@@ -44,6 +44,10 @@ extern "C" {
 #define CP_MODEL_COLBLOCK       4  /* alpha_col(w) + nets*beta_col(w) */
 #define CP_MODEL_BLOCK          5  /* rank-R separable 2-D VBR cost, needs a row partition */
 #define CP_MODEL_VERTEX_COUNT   6  /* VertexCount(): j' - j, always Int */
+#define CP_MODEL_POWER_WORK     7  /* alpha + (nv*b_vertex + np*b_pin)^gamma, Float64 only, gamma in p_f64[3]: the
+                                      ConvexWorkModel (gamma = 0.8) / ConcaveWorkModel (gamma = 2) the reference's
+                                      tests define (test/test_Partitioners.jl:54-74); gamma == 2 is evaluated as x*x
+                                      (Julia's literal_pow), any other exponent with pow() */
 
 /* parameter slots of p_i64 / p_f64 */
 #define CP_P_ALPHA      0
@@ -52,6 +56,7 @@ extern "C" {
 #define CP_P_NET        3   /* connectivity: b_net ; hyperedge: b_self_net */
 #define CP_P_SELF_NET   3
 #define CP_P_CUT_NET    4
+#define CP_P_GAMMA      3   /* power work model: the exponent */
 
 #define CP_MAX_R 4
 

@@ -121,6 +121,17 @@ int32_t orc_partition_convex(int64_t m, int64_t n, int64_t N, const int64_t *pos
                              const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
                              int64_t *spl_out);
 
+/* pack_stripe(A, ConcaveTotalChunker(...)) / partition_stripe(A, K, ConcaveTotalSplitter(...))
+ * ConcaveTotalChunker.jl:9-180 */
+int32_t orc_pack_concave(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                         const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                         const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                         int64_t *spl_out, int64_t *K_out);
+int32_t orc_partition_concave(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                              int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                              const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                              int64_t *spl_out);
+
 /* EquiSplitter / EquiChunker EquiPartitioner.jl:3-22 */
 void    orc_partition_equi(int64_t n, int64_t K, int64_t *spl_out);            /* K+1 entries */
 int64_t orc_pack_equi(int64_t n, int64_t w, int64_t *spl_out);                  /* returns K; cld(n,w)+1 entries */

@@ -33,6 +33,12 @@
     int32_t orc_api_partition_convex##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,       \
                                         int64_t, const cp_model_t *, const cp_rowpart_t *,                 \
                                         const cp_model_t *, int64_t, double, int64_t *);               \
+    int32_t orc_api_pack_concave##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,           \
+                                    const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, \
+                                    double, int64_t *, int64_t *);                                         \
+    int32_t orc_api_partition_concave##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,      \
+                                         int64_t, const cp_model_t *, const cp_rowpart_t *,                \
+                                         const cp_model_t *, int64_t, double, int64_t *);                  \
     int32_t orc_api_partition_bisect_index##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, \
                                               int64_t, const cp_model_t *, int32_t, int64_t *, int64_t *); \
     int32_t orc_api_partition_lazy_bisect_cost##S(int64_t, int64_t, int64_t, const int64_t *,              \
@@ -135,6 +141,23 @@ int32_t orc_partition_lazy_bisect_cost(int64_t m, int64_t n, int64_t N, const in
 {
     return IS_I(mdl) ? orc_api_partition_lazy_bisect_cost_i64(m, n, N, pos, idx, K, mdl, eps, spl_out, n_probes_out)
                      : orc_api_partition_lazy_bisect_cost_f64(m, n, N, pos, idx, K, mdl, eps, spl_out, n_probes_out);
+}
+
+int32_t orc_pack_concave(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                         const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                         const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                         int64_t *spl_out, int64_t *K_out)
+{
+    return IS_I(mdl) ? orc_api_pack_concave_i64(m, n, N, pos, idx, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out)
+                     : orc_api_pack_concave_f64(m, n, N, pos, idx, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+}
+
+int32_t orc_partition_concave(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                              int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                              const cp_model_t *weight, int64_t wmax_i64, double wmax_f64, int64_t *spl_out)
+{
+    return IS_I(mdl) ? orc_api_partition_concave_i64(m, n, N, pos, idx, K, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out)
+                     : orc_api_partition_concave_f64(m, n, N, pos, idx, K, mdl, Pi, weight, wmax_i64, wmax_f64, spl_out);
 }
 
 /* EquiPartitioner.jl:7 : spl[k] = (k-1)*fld(n,K) + min(n % K, k-1) + 1, k = 1..K+1 */

@@ -89,6 +89,14 @@ class OracleBackend:
         return lib().orc_partition_convex(*self._A(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
                                           wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
 
+    def pack_concave(self, A, mm, rp, wm, wi, wf, spl, Kout):
+        return lib().orc_pack_concave(*self._A(A), mm.ptr, C.byref(rp) if rp is not None else None,
+                                     wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
+
+    def partition_concave(self, A, K, mm, rp, wm, wi, wf, spl):
+        return lib().orc_partition_concave(*self._A(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
+                                          wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl))
+
     def oracle_eval(self, A, mm, rp, hint, j, jp, k, out):
         oi = out if out.dtype == np.int64 else None
         of = out if out.dtype == np.float64 else None

@@ -70,3 +70,46 @@ def test_lazy_rejects_work_models(hip):
     A = suitesparse_shaped(100, 4, 1)
     with pytest.raises(AssertionError):
         cp.partition_stripe(A, 2, cp.LazyBisectCostBottleneckSplitter(cp.AffineWorkModel(0, 10, 1), 0.1), backend=hip)
+
+
+def test_concave_methods_match_oracle(hip, orc):
+    """ConcaveTotalChunker / ConcaveTotalSplitter: identical control flow on the device (bit-exact split vectors), for
+    concave costs and -- the algorithm is deterministic for any cost -- for the affine and connectivity models too."""
+    w = cp.AffineWorkModel(0, 1, 0)
+    mats = _mats(33) + [suitesparse_shaped(3000, 6, 2), banded(2000, 8, 0.5, 3)]
+    for A in mats:
+        fs = [cp.ConcaveWorkModel(0.0, 0, 1), cp.ConcaveWorkModel(-0.7, 0, 1), cp.ConcaveWorkModel(0.5, 1, 1), cp.AffineWorkModel(0, 0, 0),
+              cp.AffineWorkModel(-2, 3, 1), cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineConnectivityModel(-0.5, 0.0, 0.0, 1.0),
+              cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 2), cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 4),
+              cp.ConstrainedCost(cp.ConcaveWorkModel(0, 0, 1), w, 8), cp.ConstrainedCost(cp.AffineConnectivityModel(0, 3, 1, 3), cp.VertexCount(), 4)]
+        for f in fs:
+            if A.n >= 1:
+                got = cp.pack_stripe(A, cp.ConcaveTotalChunker(f), backend=hip)
+                want = cp.pack_stripe(A, cp.ConcaveTotalChunker(f), backend=orc)
+                assert got == want, (A, "chunker", fs.index(f))
+            for K in (1, 2, 3, 8):
+                if A.n > 1000 and K > 3:
+                    continue
+                got = cp.partition_stripe(A, K, cp.ConcaveTotalSplitter(f), backend=hip)
+                want = cp.partition_stripe(A, K, cp.ConcaveTotalSplitter(f), backend=orc)
+                assert got == want, (A, K, "splitter", fs.index(f))
+
+
+def test_power_work_model_on_device(hip, orc):
+    """ConvexWorkModel (x^0.8, pow() within a few ulp of the host's) and ConcaveWorkModel (x*x, exact) through every
+    method that takes a model: values within 1e-12 relative, and the exact DP reaches the oracle's optimum."""
+    A = suitesparse_shaped(2000, 6, 4)
+    for f in (cp.ConvexWorkModel(0.0, 0, 1), cp.ConvexWorkModel(-0.7, 1, 1), cp.ConcaveWorkModel(0.0, 0, 1)):
+        j = np.array([1, 1, 5, 100, 1500], dtype=np.int64); jp = np.array([1, 2001, 900, 101, 2001], dtype=np.int64)
+        a = cp.oracle_stripe(cp.RandomHint(), f, A, backend=hip)(j, jp)
+        b = cp.oracle_stripe(cp.RandomHint(), f, A, backend=orc)(j, jp)
+        assert np.allclose(a, b, rtol=1e-12, atol=0)
+        for K in (2, 5):
+            got = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=hip)
+            want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=orc)
+            va, vb = cp.total_value(A, got, f, backend=orc), cp.total_value(A, want, f, backend=orc)
+            assert abs(va - vb) <= 1e-12 * max(1.0, abs(vb))
+        got = cp.pack_stripe(A, cp.ConvexTotalChunker(f), backend=hip) if f.gamma < 1 else cp.pack_stripe(A, cp.ConcaveTotalChunker(f), backend=hip)
+        ref = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=orc)
+        va, vb = cp.total_value(A, got, f, backend=orc), cp.total_value(A, ref, f, backend=orc)
+        assert abs(va - vb) <= 1e-9 * max(1.0, abs(vb))

@@ -240,3 +240,65 @@ def test_lazy_rejects_non_connectivity_models(orc):
     except AssertionError:
         return
     raise AssertionError("expected the reference's assertion")
+
+
+# ------------------------------------------------------------------ ConcaveTotalChunker / ConcaveTotalSplitter
+def _approx(a, b):
+    return abs(a - b) <= 1e-9 * max(1.0, abs(a), abs(b))
+
+
+def _widths_ok(A, Phi, w, w_max):
+    """every part satisfies the AffineWorkModel weight constraint"""
+    s = Phi.spl
+    return all(w(int(s[k + 1] - s[k]), int(A.colptr[s[k + 1] - 1] - A.colptr[s[k] - 1])) <= w_max for k in range(Phi.K))
+
+
+def test_power_work_model_values(orc):
+    """ConvexWorkModel / ConcaveWorkModel of test_Partitioners.jl:54-74 through the oracle's cost oracle."""
+    A = golden_matrices()["HB/can_292"]
+    for f in (cp.ConcaveWorkModel(0.0, 0, 1), cp.ConcaveWorkModel(-0.7, 1, 0), cp.ConvexWorkModel(0.0, 0, 1), cp.ConvexWorkModel(-0.7, 0, 1)):
+        ocl = cp.oracle_stripe(cp.RandomHint(), f, A, backend=orc)
+        for (j, jp) in ((1, 1), (1, 2), (3, 40), (1, A.n + 1), (100, 200)):
+            want = f(jp - j, int(A.colptr[jp - 1] - A.colptr[j - 1]))
+            got = ocl(j, jp)
+            assert got == want if f.gamma == 2.0 else _approx(got, want)
+
+
+def test_concave_total_splitter_is_optimal(orc):
+    """test_Partitioners.jl:201-222: same total value as ReferenceTotalSplitter on concave costs."""
+    w = cp.AffineWorkModel(0, 1, 0)
+    for A in small_matrices(50, trials=1) + [golden_matrices()["HB/can_292"]]:
+        for K in (1, 2, 3, 4, 8):
+            if A.n > 100 and K > 4:
+                continue
+            for f in (cp.ConcaveWorkModel(0, 0, 1), cp.AffineWorkModel(0, 0, 0), cp.AffineWorkModel(2, 3, 1),
+                      cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 2), cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 4),
+                      cp.ConstrainedCost(cp.ConcaveWorkModel(0, 0, 1), w, 8)):
+                ref = cp.partition_stripe(A, K, cp.ReferenceTotalSplitter(f), backend=orc)
+                got = cp.partition_stripe(A, K, cp.ConcaveTotalSplitter(f), backend=orc)
+                s = got.spl
+                assert np.all(np.diff(s) >= 0) and s[0] == 1 and s[-1] == A.n + 1 and got.K == K
+                if isinstance(f, cp.ConstrainedCost):
+                    feas_ref, feas_got = _widths_ok(A, ref, w, f.w_max), _widths_ok(A, got, w, f.w_max)
+                    assert feas_ref == feas_got                   # Extended costs: infinity == infinity
+                    if not feas_ref:
+                        continue
+                assert _approx(cp.total_value(A, got, f, backend=orc), cp.total_value(A, ref, f, backend=orc)), (A, K)
+
+
+def test_concave_total_chunker_is_optimal(orc):
+    """test_Partitioners.jl:278-299."""
+    w = cp.AffineWorkModel(0, 1, 0)
+    for A in small_matrices(51, trials=1) + [golden_matrices()["HB/can_292"]]:
+        if A.n < 1:
+            continue
+        for f in (cp.ConcaveWorkModel(0.0, 0, 1), cp.ConcaveWorkModel(-0.7, 0, 1), cp.AffineWorkModel(0, 0, 0), cp.AffineWorkModel(-2, 3, 1),
+                  cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 2), cp.ConstrainedCost(cp.ConcaveWorkModel(0, 1, 0), w, 4),
+                  cp.ConstrainedCost(cp.ConcaveWorkModel(0, 0, 1), w, 8)):
+            ref = cp.pack_stripe(A, cp.ReferenceTotalChunker(f), backend=orc)
+            got = cp.pack_stripe(A, cp.ConcaveTotalChunker(f), backend=orc)
+            s = got.spl
+            assert np.all(np.diff(s) >= 0) and s[0] == 1 and s[-1] == A.n + 1
+            if isinstance(f, cp.ConstrainedCost):
+                assert _widths_ok(A, got, w, f.w_max) and _widths_ok(A, ref, w, f.w_max)
+            assert _approx(cp.total_value(A, got, f, backend=orc), cp.total_value(A, ref, f, backend=orc)), (A, f)
