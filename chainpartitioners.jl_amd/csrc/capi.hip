@@ -102,13 +102,7 @@ static bool model_known(const cp_model_t *m)
     return m->dtype == CP_I64 || m->dtype == CP_F64;
 }
 
-static bool all_integral(const cp_model_t *m)
-{
-    if (m->dtype == CP_I64) return true;
-    for (int i = 0; i < 5; i++) if (std::floor(m->p_f64[i]) != m->p_f64[i] || std::fabs(m->p_f64[i]) > 9e15) return false;
-    if (m->alpha_k) for (int64_t i = 0; i < m->n_alpha_k; i++) { double v = ((const double *)m->alpha_k)[i]; if (std::floor(v) != v) return false; }
-    return true;
-}
+static bool all_integral(const cp_model_t *m) { return model_all_integral(m); }
 
 // is the O(n log^2 n) total-cost scheme exact for this model?  Needs W[p]+f(p,r) inverse-Monge:
 // modular terms (alpha, vertices, pins) are free; the net count is submodular, so beta_net >= 0;

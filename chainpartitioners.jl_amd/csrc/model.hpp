@@ -7,6 +7,7 @@
 //   ColumnBlockComponentCostModel  alpha_col(w) + nn*beta_col(w)                   BlockCosts.jl:17
 #pragma once
 #include "common.hpp"
+#include <cmath>
 
 namespace cpk {
 
@@ -98,6 +99,17 @@ __device__ __forceinline__ TC comb(int32_t g, TC a, TC b)
 {
     if (g == CP_COMBINE_SUM) return cadd(a, b);
     return a > b ? a : b;
+}
+
+// Int64 model, or a Float64 model whose scalar parameters are all integer-valued (then every cost is an exactly
+// represented integer and sums are associative below 2^53)
+inline bool model_all_integral(const cp_model_t *m)
+{
+    if (m->dtype == CP_I64) return true;
+    if (m->kind == CP_MODEL_POWER_WORK) return false;
+    for (int i = 0; i < 5; i++) if (std::floor(m->p_f64[i]) != m->p_f64[i] || std::fabs(m->p_f64[i]) > 9e15) return false;
+    if (m->alpha_k) for (int64_t i = 0; i < m->n_alpha_k; i++) { double v = ((const double *)m->alpha_k)[i]; if (std::floor(v) != v) return false; }
+    return true;
 }
 
 // host: build a DevModel from the C-ABI struct, uploading alpha_k / tables

@@ -14,6 +14,8 @@
 #include "csr.hpp"
 #include "model.hpp"
 #include "wavelet.hpp"
+#include "dp.hpp"
+#include <type_traits>
 #include <memory>
 
 namespace cpk {
@@ -700,7 +702,14 @@ int32_t run_pack_dynamic(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t 
     CP_HIP(hipMemsetAsync(spl.p, 0, spl.bytes(), s));
     {
         ProfScope ps(PROF_CHUNK, s, 0.0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_dynamic<TC>), dim3(1), dim3(64), 0, s, C->O, W, cst.p, spl.p, st.p);
+        // width-windowed costs whose sums are exact: parallel (min,+) scan (chunk_scan.hip); tables of block-component
+        // models hold tabulated component values, which the host marshals as exact integers too
+        bool scanned = false;
+        bool exact = std::is_same<TC, int64_t>::value || (model_all_integral(mdl) && mdl->kind != CP_MODEL_COLBLOCK);
+        if (W.kind == CP_MODEL_VERTEX_COUNT && C->O.Ftab && C->O.Wc == wi && exact && !g_opt_force_brute)
+            scanned = pack_dynamic_scan<TC>(s, n, wi, C->O.Ftab, cst.p, spl.p);
+        if (!scanned)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_dynamic<TC>), dim3(1), dim3(64), 0, s, C->O, W, cst.p, spl.p, st.p);
     }
     CP_HIP(hipGetLastError());
     int32_t rc = 0;

@@ -80,3 +80,31 @@ def test_block_costs(hip, orc):
                 want = cp.pack_stripe(A, cp.DynamicTotalChunker(f), Pi, backend=orc)
                 assert got == want
                 assert np.all(np.diff(got.spl) <= 4)
+
+
+def test_pack_dynamic_scan_path(hip, orc):
+    """Width-windowed DynamicTotalChunker takes the parallel (min,+) scan (csrc/chunk_scan.hip): same split vector as the
+    oracle, and as the one-wave literal kernel (cp_set_option("force_brute")), across window widths, block boundaries
+    of the scan (n around multiples of 64) and models with negative costs / frequent ties."""
+    fs = [cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(-7, 0, 0, 1),
+          cp.AffineWorkModel(0, 0, 0), cp.AffineWorkModel(-3, 1, 0), cp.AffineHyperedgeCutModel(0, 1, 1, 1, 3),
+          cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w), cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0),
+          cp.AffineConnectivityModel(-0.5, 0.0, 0.0, 1.0)]
+    for n in (1, 2, 63, 64, 65, 129, 1000, 4097, 20000):
+        A = banded(n, 5, 0.5, n) if n % 2 else suitesparse_shaped(n, 4, n)
+        for f in fs:
+            for w in (1, 2, 3, 5, 8, 9, 16, 17):
+                if n > 5000 and w not in (3, 8, 16):
+                    continue
+                fc = cp.ConstrainedCost(f, cp.VertexCount(), w)
+                got = cp.pack_stripe(A, cp.DynamicTotalChunker(fc), backend=hip)
+                if n <= 5000:
+                    want = cp.pack_stripe(A, cp.DynamicTotalChunker(fc), backend=orc)
+                    assert got == want, (n, w, fs.index(f))
+                hip.set_option("force_brute", 1)
+                try:
+                    lit = cp.pack_stripe(A, cp.DynamicTotalChunker(fc), backend=hip)
+                finally:
+                    hip.set_option("force_brute", 0)
+                assert got == lit, (n, w, fs.index(f), "scan vs literal kernel")
+                assert np.all(np.diff(got.spl) <= w)
