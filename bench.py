@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--nnz", type=int, default=100_000_000)
     ap.add_argument("--parts", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["connectivity", "hyperedge"], default="connectivity",
+                    help="connectivity = BASELINE config 3 (default, the metric); hyperedge = the config-5 cost "
+                         "AffineHyperedgeCutModel(0,0,0,0,1) for scale checks")
     ap.add_argument("--dbg", type=int, default=0, help="timing experiments only (wrong results)")
     ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
                     help="N>1: 'independent' = one partition per GPU (weak scaling, default); 'tiled' = ONE partition whose DP rows "
@@ -123,7 +126,7 @@ def main():
     N = int(rowval.numel())
     torch.cuda.synchronize()
     h = hip.csr_from_device(n, n, N, colptr.data_ptr(), rowval.data_ptr())
-    mdl = cp.AffineConnectivityModel(0, 0, 0, 1)
+    mdl = cp.AffineConnectivityModel(0, 0, 0, 1) if args.model == "connectivity" else cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1)
     mm = mdl.marshal()
     spl = np.zeros(K + 1, dtype=np.int64)
     if args.dbg:
@@ -193,12 +196,13 @@ def main():
         if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
             traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
         out = {
-            "metric": "partitions/sec, DynamicTotalSplitter(AffineConnectivityModel{Int64}(0,0,0,1)), K=%d" % K,
+            "metric": "partitions/sec, DynamicTotalSplitter(%s), K=%d"
+                      % ("AffineConnectivityModel{Int64}(0,0,0,1)" if args.model == "connectivity" else "AffineHyperedgeCutModel{Int64}(0,0,0,0,1)", K),
             "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "DynamicSplitter + ConnectivityCosts (lambda-1) on suitesparse_shaped CSR, "
-                                   "n=%d rows, nnz=%d, K=%d; %s" % (n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
+            "config": {"workload": "DynamicSplitter + %s on suitesparse_shaped CSR, "
+                                   "n=%d rows, nnz=%d, K=%d; %s" % ("ConnectivityCosts (lambda-1)" if args.model == "connectivity" else "HyperedgeCutCosts (cut nets)", n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
                        "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
             "roofline": {"bound": "hbm", "kernel": "dp_lpass (k_lpass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
