@@ -25,6 +25,7 @@
 #include "csr.hpp"
 #include "model.hpp"
 #include "dp.hpp"
+#include <algorithm>
 
 namespace cpk {
 
@@ -116,12 +117,15 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
         cnt[b] = 0;
     }
     int64_t q0 = pos[c0], q1 = pos[c1];
-    for (int64_t q = q0 + lane; q < q1; q += 64) {
-        int32_t v = prev[q];
+    const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
+    for (int64_t q = q0 + lane; q < q1; q += 256) {            // four independent coalesced loads in flight
+        int32_t v0 = prev[q], v1 = q + 64 < q1 ? prev[q + 64] : NEVER, v2 = q + 128 < q1 ? prev[q + 128] : NEVER,
+                v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
             if (b <= tau || b >= nbits) continue;              // wave-uniform
-            cnt[b] += ge ? (v >= thr[b]) : (v < thr[b]);
+            int32_t t = thr[b];
+            cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
         }
     }
 #pragma unroll
@@ -296,9 +300,7 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
                 int32_t xc = x + c * 256;
                 if (xc >= q_hi) break;                    // wave-uniform
                 int4 v = c ? v1 : v0;
-                int32_t pb = xc + 4 * lane;               // position of component 0
-                bool in0 = pb >= q_lo && pb < q_hi, in1 = pb + 1 >= q_lo && pb + 1 < q_hi;
-                bool in2 = pb + 2 >= q_lo && pb + 2 < q_hi, in3 = pb + 3 >= q_lo && pb + 3 < q_hi;
+                // (entries outside the run need no masking: a lane only counts inside its own range, which lies in the run)
                 bool ov = mine && s < xc + 256 && en > xc;
                 // this lane's range covers positions [a0, a1) of the block: lanes [lo_j, hi_j) of component j
                 int a0 = ov ? ((s > xc ? s : xc) - xc) : 0, a1 = ov ? ((en < xc + 256 ? en : xc + 256) - xc) : 0;
@@ -307,8 +309,8 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
                     int l = __ffsll((long long)rem) - 1;
                     int32_t tu = __shfl(thr, l);
                     unsigned long long m0, m1, m2, m3;
-                    if (GE) { m0 = __ballot(in0 && v.x >= tu); m1 = __ballot(in1 && v.y >= tu); m2 = __ballot(in2 && v.z >= tu); m3 = __ballot(in3 && v.w >= tu); }
-                    else    { m0 = __ballot(in0 && v.x < tu);  m1 = __ballot(in1 && v.y < tu);  m2 = __ballot(in2 && v.z < tu);  m3 = __ballot(in3 && v.w < tu); }
+                    if (GE) { m0 = __ballot(v.x >= tu); m1 = __ballot(v.y >= tu); m2 = __ballot(v.z >= tu); m3 = __ballot(v.w >= tu); }
+                    else    { m0 = __ballot(v.x < tu);  m1 = __ballot(v.y < tu);  m2 = __ballot(v.z < tu);  m3 = __ballot(v.w < tu); }
                     bool same = ov && thr == tu;
                     if (same) {
 #define CP_CNT(mj, j)                                                                                   \
@@ -326,6 +328,48 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
                     }
                     rem &= ~__ballot(same);
                 }
+            }
+        }
+    }
+    return d;
+}
+
+// Same counts for the interior tiles of a long task: the valid lanes 0 .. nvalid-1 hold adjacent descending columns of ONE
+// task (one run, one threshold): no run detection, one ballot pass per 256-entry block.
+template <bool GE>
+__device__ __forceinline__ int32_t coop_count_run(const int32_t *__restrict__ arr, int32_t s, int32_t en, int32_t thr, bool valid, int lane, int nvalid)
+{
+    int32_t d = 0;
+    if (nvalid <= 0) return d;
+    const int32_t FILL = GE ? INT32_MIN : INT32_MAX;
+    int32_t q_hi = __shfl(en, 0), q_lo = __shfl(s, nvalid - 1);
+    for (int32_t x = q_lo & ~3; x < q_hi; x += 512) {
+        int4 v0 = make_int4(FILL, FILL, FILL, FILL), v1 = v0;
+        int32_t b0 = x + 4 * lane, b1 = b0 + 256;
+        if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(arr + b0);
+        if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(arr + b1);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int32_t xc = x + c * 256;
+            if (xc >= q_hi) break;                        // wave-uniform
+            int4 v = c ? v1 : v0;
+            unsigned long long m0, m1, m2, m3;
+            if (GE) { m0 = __ballot(v.x >= thr); m1 = __ballot(v.y >= thr); m2 = __ballot(v.z >= thr); m3 = __ballot(v.w >= thr); }
+            else    { m0 = __ballot(v.x < thr);  m1 = __ballot(v.y < thr);  m2 = __ballot(v.z < thr);  m3 = __ballot(v.w < thr); }
+            bool ov = valid && s < xc + 256 && en > xc;
+            if (ov) {
+                int a0 = (s > xc ? s : xc) - xc, a1 = (en < xc + 256 ? en : xc + 256) - xc;
+#define CP_CNT(mj, j)                                                                                   \
+    {                                                                                                   \
+        int lo_ = (a0 - (j) + 3) >> 2, hi_ = (a1 - (j) + 3) >> 2;                                       \
+        if (hi_ > lo_) {                                                                                \
+            int w_ = hi_ - lo_;                                                                         \
+            unsigned long long mm_ = (w_ >= 64) ? ~0ull : (((1ull << w_) - 1) << lo_);                 \
+            d += __popcll((mj) & mm_);                                                                  \
+        }                                                                                               \
+    }
+                CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
+#undef CP_CNT
             }
         }
     }
@@ -356,10 +400,51 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     bool active = tile_start < T;
     int32_t *s_off = s_off_all[wave];
     unsigned long long *s_hd = s_hd_all[wave];
-    int64_t t0 = active ? a_tile_t0[tile] : 0; int cnt;
-    load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
+    int64_t t0 = active ? a_tile_t0[tile] : 0; int cnt = 0;
+    // interior tile: every step belongs to ONE task whose head lies in an earlier tile (four out of five tiles: the
+    // D&C re-scans the wide gaps of the arg-min staircase at every level).  Wave-uniform fast path: no task lookup, one
+    // threshold, plain scans, nothing to evaluate here (k_open finishes these tiles from `loc`).
+    bool interior = false;
+    int64_t toff0 = 0;
+    if (active) {
+        toff0 = a_offs[t0];
+        int64_t nx = a_offs[t0 + 1], tend = tile_start + LT < T ? tile_start + LT : T;
+        interior = toff0 < tile_start && nx >= tend;
+    }
+    if (!interior) load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     __syncthreads();
     if (!active) return;
+    if (interior) {
+        int4 td = a_tdesc[t0];
+        int32_t B = td.x, r = td.z;
+        int32_t rel = (int32_t)(tile_start - toff0);             // element index of the tile's first step (>= 1)
+        int32_t tl = (T - tile_start < LT) ? (int32_t)(T - tile_start) - 1 : LT - 1;
+        int32_t carry = 0, carry2 = 0;
+        for (int g = 0; g < LT / 64; g++) {
+            int32_t e = g * 64 + lane;
+            bool valid = e <= tl;
+            int32_t p = B - (rel + e);
+            int32_t s = 0, en = 0, s2 = 0, en2 = 0;
+            if (valid) { s = a_pos[p]; en = a_pos[p + 1]; if (HYP) { s2 = a_fpos[p]; en2 = a_fpos[p + 1]; } }
+            int nvalid = tl - g * 64 + 1; nvalid = nvalid > 64 ? 64 : nvalid;
+            int32_t x = coop_count_run<true>(a_next, s, en, r, valid, lane, nvalid);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int32_t pv = __shfl_up(x, o); if (lane >= o) x += pv; }
+            x += carry;
+            carry = __shfl(x, 63);
+            if (valid) a_loc[tile_start + e] = x;
+            if (HYP) {
+                int32_t x2 = coop_count_run<false>(a_flast, s2, en2, r, valid, lane, nvalid);
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { int32_t pv = __shfl_up(x2, o); if (lane >= o) x2 += pv; }
+                x2 += carry2;
+                carry2 = __shfl(x2, 63);
+                if (valid) a_loc2[tile_start + e] = x2;
+            }
+        }
+        if (lane == 0) { a_tileS[tile] = carry; if (HYP) a_tileS2[tile] = carry2; }
+        return;
+    }
     // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
     int head_at0 = (s_off[0] == 0) ? 1 : 0;
     int hd_before = 0;                                  // heads in the groups already processed
@@ -444,7 +529,86 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     if (lane == 0) { a_tileS[tile] = carryS; if (HYP) a_tileS2[tile] = carryS2; }   // counts since the last head of the tile
 }
 
-// ------------------------------------------------------------------ open-left part of a tile (task started in an earlier tile)
+// ------------------------------------------------------------------ tasks that span tiles
+// A task whose steps continue beyond its head tile is finished in one of two ways:
+//  * short spans (the task ends in the next tile, at most SPAN_SHORT steps there): ONE LANE evaluates the remaining
+//    steps from the counts k_lpass left in `loc`, merges them with the head tile's partial and writes the winner
+//    (k_span_short, one lane per tile -- at low tau nearly every tile boundary cuts a short task);
+//  * long spans: every covered tile is reduced by one wave (k_open), then one wave per head tile merges the
+//    partials (k_fix).  k_span_short appends those tiles to two work lists; the wave kernels walk the lists.
+constexpr int SPAN_SHORT = 32;
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
+                                                    const int4 *__restrict__ a_tdesc, const int32_t *__restrict__ a_tS0l,
+                                                    const uint8_t *__restrict__ a_tb, const int32_t *__restrict__ a_pos,
+                                                    const int32_t *__restrict__ a_loc, const int32_t *__restrict__ a_loc2,
+                                                    const int64_t *__restrict__ a_tile_t0, const int64_t *__restrict__ a_taskR,
+                                                    const int32_t *__restrict__ a_tileS, const int32_t *__restrict__ a_tileS2,
+                                                    const Best<TC, HYP> *__restrict__ partR, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                    int32_t *__restrict__ a_opt, int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
+                                                    int32_t *__restrict__ open_list, int32_t *__restrict__ fix_list, int32_t *__restrict__ counts)
+{
+    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    bool in = tile < ntile;
+    int64_t n1 = R.n + 1;
+    // ---- role 1: this tile is the head tile of a task that continues beyond it
+    bool fix_long = false;
+    if (in) {
+        int64_t t = a_taskR[tile];
+        if (t >= 0) {
+            int64_t end = a_offs[t + 1] - 1, ntl = (tile + 1) * LT;
+            int64_t open_len = end - ntl + 1;
+            if (end / LT == tile + 1 && open_len <= SPAN_SHORT) {
+                int4 td = a_tdesc[t];
+                int64_t toff = a_offs[t];
+                int64_t B = td.x, r = td.z;
+                int64_t base = (int64_t)td.y + a_tileS[tile];           // counts up to the end of the head tile
+                int64_t base2 = HYP ? (int64_t)a_tS0l[t] + a_tileS2[tile] : 0;
+                Best<TC, HYP> best = partR[tile];
+                for (int64_t e = ntl; e <= end; e++) {                  // decreasing p: earlier candidates win ties
+                    int64_t p = B - (e - toff);
+                    int64_t nn = base + a_loc[e], nl = HYP ? base2 + a_loc2[e] : 0;
+                    TC fv = dm_apply(M, alpha, r - p, (int64_t)(td.w - a_pos[p]), nn, nl);
+                    Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
+                    best = better(best, c);
+                }
+                int b = a_tb[t];
+                a_opt[(int64_t)b * n1 + r] = best.p;
+                a_nnopt[(int64_t)b * n1 + r] = best.nn;
+                if (HYP) a_nlopt[(int64_t)b * n1 + r] = best_nl(best);
+            } else {
+                fix_long = true;
+            }
+        }
+    }
+    // ---- role 2: this tile starts inside a task of a long span
+    bool open_long = false;
+    if (in) {
+        int64_t tile_start = tile * LT;
+        int64_t t0 = a_tile_t0[tile];
+        int64_t toff0 = a_offs[t0];
+        if (toff0 < tile_start) {
+            int64_t end0 = a_offs[t0 + 1] - 1, h = toff0 / LT;
+            bool is_short = (end0 / LT == h + 1) && (end0 - tile_start + 1 <= SPAN_SHORT);
+            open_long = !is_short;
+        }
+    }
+    // wave-aggregated appends
+    unsigned long long mo = __ballot(open_long), mf = __ballot(fix_long);
+    int32_t bo = 0, bf = 0;
+    if (lane == 0) {
+        if (mo) bo = atomicAdd(&counts[0], (int32_t)__popcll(mo));
+        if (mf) bf = atomicAdd(&counts[1], (int32_t)__popcll(mf));
+    }
+    bo = __shfl(bo, 0); bf = __shfl(bf, 0);
+    unsigned long long below = (1ull << lane) - 1ull;
+    if (open_long) open_list[bo + __popcll(mo & below)] = (int32_t)tile;
+    if (fix_long) fix_list[bf + __popcll(mf & below)] = (int32_t)tile;
+}
+
+// open-left part of a tile of a long span (the task started in an earlier tile): one wave per listed tile
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
                                               const int4 *__restrict__ a_tdesc,
@@ -453,77 +617,82 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
                                               const int32_t *__restrict__ a_loc2, const int64_t *__restrict__ a_tile_t0,
                                               const int64_t *__restrict__ tilePS,
                                               const int64_t *__restrict__ tilePS2, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                              Best<TC, HYP> *__restrict__ partL)
+                                              Best<TC, HYP> *__restrict__ partL, const int32_t *__restrict__ open_list, const int32_t *__restrict__ counts)
 {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= ntile) return;
-    int64_t tile_start = tile * LT;
-    int64_t t = a_tile_t0[tile];                        // task of the tile's first step
-    int64_t toff = a_offs[t];
-    if (toff >= tile_start) return;                     // tile starts with a head: nothing open on the left
-    int64_t last = a_offs[t + 1] - 1;
-    int64_t tile_last = tile_start + LT - 1;
-    if (tile_last > T - 1) tile_last = T - 1;
-    if (last > tile_last) last = tile_last;
-    int4 td = a_tdesc[t];
-    int64_t r = td.z, B = td.x;
-    // counts of this task in earlier tiles: its head tile contributes "since the last head", every tile in
-    // between is covered entirely by the task: a range sum over the per-tile tails (tilePS = their prefix sums)
-    int64_t base = (int64_t)td.y + (tilePS[tile] - tilePS[toff / LT]);
-    int64_t base2 = HYP ? (int64_t)a_tS0l[t] + (tilePS2[tile] - tilePS2[toff / LT]) : 0;
-    Best<TC, HYP> best; best_clear(best);
-    for (int64_t e = tile_start + lane; e <= last; e += 64) {
-        int64_t p = B - (e - toff);
-        int64_t nn = base + a_loc[e], nl = HYP ? base2 + a_loc2[e] : 0;
-        TC fv = dm_apply(M, alpha, r - p, (int64_t)(td.w - a_pos[p]), nn, nl);
-        Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
-        best = better(best, c);                         // a lane visits its steps in increasing e (decreasing p)
+    int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t cnt = counts[0];
+    for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < cnt; w += nw) {
+        int64_t tile = open_list[w];
+        int64_t tile_start = tile * LT;
+        int64_t t = a_tile_t0[tile];                        // task of the tile's first step
+        int64_t toff = a_offs[t];
+        int64_t last = a_offs[t + 1] - 1;
+        int64_t tile_last = tile_start + LT - 1;
+        if (tile_last > T - 1) tile_last = T - 1;
+        if (last > tile_last) last = tile_last;
+        int4 td = a_tdesc[t];
+        int64_t r = td.z, B = td.x;
+        // counts of this task in earlier tiles: its head tile contributes "since the last head", every tile in
+        // between is covered entirely by the task: a range sum over the per-tile tails (tilePS = their prefix sums)
+        int64_t base = (int64_t)td.y + (tilePS[tile] - tilePS[toff / LT]);
+        int64_t base2 = HYP ? (int64_t)a_tS0l[t] + (tilePS2[tile] - tilePS2[toff / LT]) : 0;
+        Best<TC, HYP> best; best_clear(best);
+        for (int64_t e = tile_start + lane; e <= last; e += 64) {
+            int64_t p = B - (e - toff);
+            int64_t nn = base + a_loc[e], nl = HYP ? base2 + a_loc2[e] : 0;
+            TC fv = dm_apply(M, alpha, r - p, (int64_t)(td.w - a_pos[p]), nn, nl);
+            Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
+            best = better(best, c);                         // a lane visits its steps in increasing e (decreasing p)
+        }
+        // wave arg-min; ties -> larger p
+        for (int o = 32; o > 0; o >>= 1) {
+            int src = (lane + o) & 63;
+            Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
+            if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
+            bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
+            if (lane + o < 64 && take) best = c;
+        }
+        if (lane == 0) partL[tile] = best;
     }
-    // wave arg-min; ties -> larger p
-    for (int o = 32; o > 0; o >>= 1) {
-        int src = (lane + o) & 63;
-        Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
-        if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
-        bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
-        if (lane + o < 64 && take) best = c;
-    }
-    if (lane == 0) partL[tile] = best;
 }
 
-// a task whose steps span several tiles: combine the head tile's partial with the partials of the tiles it covers
-// (one wave per tile; only head tiles of spanning tasks do work)
+// a task of a long span: combine the head tile's partial with the partials of the tiles it covers
+// (one wave per listed head tile)
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
                                              const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
                                              const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
-                                             int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
+                                             int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
+                                             const int32_t *__restrict__ fix_list, const int32_t *__restrict__ counts)
 {
     int lane = threadIdx.x & 63;
-    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntile) return;
-    int64_t t = taskR[tile];
-    if (t < 0) return;
-    int64_t end_tile = (offs[t + 1] - 1) / LT;
-    Best<TC, HYP> acc; best_clear(acc);
-    for (int64_t k = tile + 1 + lane; k <= end_tile; k += 64) {
-        Best<TC, HYP> c = partL[k];
-        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
-        if (take) acc = c;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        int src = (lane + o) & 63;
-        Best<TC, HYP> c; best_clear(c); c.v = shfl64(acc.v, src); c.p = __shfl(acc.p, src); c.nn = __shfl(acc.nn, src);
-        if (HYP) best_set_nl(c, __shfl(best_nl(acc), src));
-        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
-        if (lane + o < 64 && take) acc = c;
-    }
-    if (lane == 0) {
-        Best<TC, HYP> res = better(partR[tile], acc);   // the head tile holds the larger p: wins ties
-        int64_t r = tdesc[t].z; int b = tb[t];
-        opt[(int64_t)b * n1 + r] = res.p;
-        nnopt[(int64_t)b * n1 + r] = res.nn;
-        if (HYP) nlopt[(int64_t)b * n1 + r] = best_nl(res);
+    int64_t nw = (int64_t)gridDim.x * 4;
+    int64_t cnt = counts[1];
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < cnt; w += nw) {
+        int64_t tile = fix_list[w];
+        int64_t t = taskR[tile];
+        int64_t end_tile = (offs[t + 1] - 1) / LT;
+        Best<TC, HYP> acc; best_clear(acc);
+        for (int64_t k = tile + 1 + lane; k <= end_tile; k += 64) {
+            Best<TC, HYP> c = partL[k];
+            bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+            if (take) acc = c;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int src = (lane + o) & 63;
+            Best<TC, HYP> c; best_clear(c); c.v = shfl64(acc.v, src); c.p = __shfl(acc.p, src); c.nn = __shfl(acc.nn, src);
+            if (HYP) best_set_nl(c, __shfl(best_nl(acc), src));
+            bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+            if (lane + o < 64 && take) acc = c;
+        }
+        if (lane == 0) {
+            Best<TC, HYP> res = better(partR[tile], acc);   // the head tile holds the larger p: wins ties
+            int64_t r = tdesc[t].z; int b = tb[t];
+            opt[(int64_t)b * n1 + r] = res.p;
+            nnopt[(int64_t)b * n1 + r] = res.nn;
+            if (HYP) nlopt[(int64_t)b * n1 + r] = best_nl(res);
+        }
     }
 }
 
@@ -562,6 +731,7 @@ struct LayerWork {
     DBuf<uint8_t> tb;
     DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
     DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
+    DBuf<int32_t> open_list, fix_list, counts;          // tiles of long spans (k_span_short -> k_open / k_fix)
     int64_t max_tasks = 0;
 };
 
@@ -705,10 +875,13 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (Wk.tileS.n < (size_t)ntile) {
             Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
             Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
+            Wk.open_list.alloc((size_t)ntile); Wk.fix_list.alloc((size_t)ntile);
+            if (!Wk.counts.p) Wk.counts.alloc(2);
             if (hyp) { Wk.tileS2.alloc((size_t)ntile); Wk.tilePS2.alloc((size_t)ntile + 1); }
         }
         if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
+        CP_HIP(hipMemsetAsync(Wk.counts.p, 0, 2 * sizeof(int32_t), s));
         hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, Wk.tile_t0.p);
         {
             // algorithmic bytes of one launch: per flattened step the stepped column's link
@@ -727,20 +900,36 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             exclusive_scan_i32(Wk.tileS.p, Wk.tilePS.p, ntile, Wk.scratch, s);
             if (hyp) exclusive_scan_i32(Wk.tileS2.p, Wk.tilePS2.p, ntile, Wk.scratch, s);
         }
+        unsigned wgrid = (unsigned)std::min<int64_t>(cdiv(ntile, 4), 8192);     // the wave kernels walk work lists
         {
             ProfScope ps(PROF_EVAL, s, 0.0);
+#define SP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.taskR.p, Wk.tileS.p, Wk.tileS2.p
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, true>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
+                               Wk.partR.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.open_list.p, Wk.fix_list.p, Wk.counts.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, false>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
+                               reinterpret_cast<const Best<TC, false> *>(Wk.partR.p), W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
+                               Wk.open_list.p, Wk.fix_list.p, Wk.counts.p);
+#undef SP_ARGS
+            if (g_opt_dbg & 16) {
+                int32_t hc[2] = {0, 0};
+                CP_HIP(hipMemcpyAsync(hc, Wk.counts.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+                CP_HIP(hipStreamSynchronize(s));
+                fprintf(stderr, "  span lists: isA=%d tau=%d ntile=%lld open_long=%d fix_long=%d\n", R.isA, R.tau, (long long)ntile, hc[0], hc[1]);
+            }
 #define OP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.tilePS.p
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, Wk.tilePS2.p, W, M, alpha, Wk.partL.p);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, OP_ARGS, (const int64_t *)nullptr, W, M, alpha, reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, true>), dim3(wgrid), dim3(256), 0, s, OP_ARGS, Wk.tilePS2.p, W, M, alpha, Wk.partL.p,
+                               Wk.open_list.p, Wk.counts.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, false>), dim3(wgrid), dim3(256), 0, s, OP_ARGS, (const int64_t *)nullptr, W, M, alpha,
+                               reinterpret_cast<Best<TC, false> *>(Wk.partL.p), Wk.open_list.p, Wk.counts.p);
 #undef OP_ARGS
         }
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
-                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.fix_list.p, Wk.counts.p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
-                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
+                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.fix_list.p, Wk.counts.p);
         }
         CP_HIP(hipGetLastError());
     }
