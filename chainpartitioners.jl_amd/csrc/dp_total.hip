@@ -236,7 +236,8 @@ __device__ __forceinline__ void wave_segmin(Best<TC, HYP> &x, int &f, int lane)
 
 // ------------------------------------------------------------------ tile task table (one wave = one tile)
 // first task overlapping each tile: last t with offs[t] <= tile*LT (one thread per tile; offs[0] = 0)
-__global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ offs, int64_t ntask, int64_t ntile, int64_t *__restrict__ tile_t0)
+__global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ offs, int64_t ntask, int64_t ntile, int64_t T,
+                                                 const int4 *__restrict__ tdesc, int64_t *__restrict__ tile_t0, int4 *__restrict__ tile_rec)
 {
     int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= ntile) return;
@@ -247,6 +248,14 @@ __global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ off
         if (offs[mid] <= tile_start) lo = mid; else hi = mid;
     }
     tile_t0[tile] = lo;
+    // interior tile: every step belongs to ONE task whose head lies in an earlier tile.  Record {first column, row, 0, 1}.
+    int64_t toff = offs[lo], nx = offs[lo + 1], tend = tile_start + LT < T ? tile_start + LT : T;
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (toff < tile_start && nx >= tend) {
+        int4 td = tdesc[lo];
+        rec = make_int4(td.x - (int32_t)(tile_start - toff), td.z, 0, 1);
+    }
+    tile_rec[tile] = rec;
 }
 
 // loads the offsets (relative to the tile start, 32-bit) of the tasks overlapping the tile and a bitmap of the
@@ -334,46 +343,62 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
     return d;
 }
 
-// Same counts for the interior tiles of a long task: the valid lanes 0 .. nvalid-1 hold adjacent descending columns of ONE
-// task (one run, one threshold): no run detection, one ballot pass per 256-entry block.
+// Interior tiles of a long task: the tile's steps e = 0 .. tl are adjacent descending columns p_first - e of ONE task, so
+// the step order is the (reversed) entry order of one contiguous run [Q_lo, Q_hi) and the inclusive step prefix is a
+// suffix count:  x(e) = #{q in [s(e), Q_hi) : flagged(q)},  s(e) = first entry of the step's column.  No per-column
+// counts, no wave scan, no carry.  The run is streamed once in 256-entry blocks (the next 512 entries are in flight while
+// a block is counted); per block: four ballots, a per-lane popcount prefix, and one gather per step whose column starts
+// inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
 template <bool GE>
-__device__ __forceinline__ int32_t coop_count_run(const int32_t *__restrict__ arr, int32_t s, int32_t en, int32_t thr, bool valid, int lane, int nvalid)
+__device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
+                                                int32_t thr, int lane, int32_t acc[4])
 {
-    int32_t d = 0;
-    if (nvalid <= 0) return d;
-    const int32_t FILL = GE ? INT32_MIN : INT32_MAX;
-    int32_t q_hi = __shfl(en, 0), q_lo = __shfl(s, nvalid - 1);
-    for (int32_t x = q_lo & ~3; x < q_hi; x += 512) {
-        int4 v0 = make_int4(FILL, FILL, FILL, FILL), v1 = v0;
-        int32_t b0 = x + 4 * lane, b1 = b0 + 256;
-        if (b0 < q_hi) v0 = *reinterpret_cast<const int4 *>(arr + b0);
-        if (b1 < q_hi) v1 = *reinterpret_cast<const int4 *>(arr + b1);
+    const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
+    int32_t sk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; sk[k] = e <= tl ? cpos[p_first - e] : INT32_MAX; acc[k] = 0; }
+    int32_t Q_hi = cpos[p_first + 1], Q_lo = cpos[p_first - tl];              // wave-uniform
+    unsigned long long below = (1ull << lane) - 1ull;
+    int32_t x = Q_lo & ~3;
+    int4 c0 = make_int4(FILL, FILL, FILL, FILL), c1 = c0;
+    if (x + 4 * lane < Q_hi) c0 = *reinterpret_cast<const int4 *>(arr + x + 4 * lane);          // arrays are padded by 8 entries
+    if (x + 256 + 4 * lane < Q_hi) c1 = *reinterpret_cast<const int4 *>(arr + x + 256 + 4 * lane);
+    for (; x < Q_hi; x += 512) {
+        int4 n0 = make_int4(FILL, FILL, FILL, FILL), n1 = n0;
+        if (x + 512 + 4 * lane < Q_hi) n0 = *reinterpret_cast<const int4 *>(arr + x + 512 + 4 * lane);
+        if (x + 768 + 4 * lane < Q_hi) n1 = *reinterpret_cast<const int4 *>(arr + x + 768 + 4 * lane);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             int32_t xc = x + c * 256;
-            if (xc >= q_hi) break;                        // wave-uniform
-            int4 v = c ? v1 : v0;
+            if (xc >= Q_hi) break;                        // wave-uniform
+            int4 v = c ? c1 : c0;
+            int32_t pb = xc + 4 * lane;
+            // entries at or above Q_hi belong to columns above the tile: never flagged (those below Q_lo lie below every s)
             unsigned long long m0, m1, m2, m3;
-            if (GE) { m0 = __ballot(v.x >= thr); m1 = __ballot(v.y >= thr); m2 = __ballot(v.z >= thr); m3 = __ballot(v.w >= thr); }
-            else    { m0 = __ballot(v.x < thr);  m1 = __ballot(v.y < thr);  m2 = __ballot(v.z < thr);  m3 = __ballot(v.w < thr); }
-            bool ov = valid && s < xc + 256 && en > xc;
-            if (ov) {
-                int a0 = (s > xc ? s : xc) - xc, a1 = (en < xc + 256 ? en : xc + 256) - xc;
-#define CP_CNT(mj, j)                                                                                   \
-    {                                                                                                   \
-        int lo_ = (a0 - (j) + 3) >> 2, hi_ = (a1 - (j) + 3) >> 2;                                       \
-        if (hi_ > lo_) {                                                                                \
-            int w_ = hi_ - lo_;                                                                         \
-            unsigned long long mm_ = (w_ >= 64) ? ~0ull : (((1ull << w_) - 1) << lo_);                 \
-            d += __popcll((mj) & mm_);                                                                  \
-        }                                                                                               \
-    }
-                CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
-#undef CP_CNT
+            if (GE) { m0 = __ballot(pb < Q_hi && v.x >= thr); m1 = __ballot(pb + 1 < Q_hi && v.y >= thr);
+                      m2 = __ballot(pb + 2 < Q_hi && v.z >= thr); m3 = __ballot(pb + 3 < Q_hi && v.w >= thr); }
+            else    { m0 = __ballot(pb < Q_hi && v.x < thr); m1 = __ballot(pb + 1 < Q_hi && v.y < thr);
+                      m2 = __ballot(pb + 2 < Q_hi && v.z < thr); m3 = __ballot(pb + 3 < Q_hi && v.w < thr); }
+            int32_t tot = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);                       // uniform
+            int32_t P0 = __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int32_t idx = sk[k] - xc;                 // block position of the step's first entry (huge for invalid steps)
+                bool inside = idx > 0 && idx < 256;
+                if (__ballot(inside)) {                   // wave-uniform: some column of this group starts inside the block
+                    int32_t cidx = inside ? idx : 0;
+                    int src = cidx >> 2, comp = cidx & 3;
+                    int32_t Ps = __shfl(P0, src);
+                    uint32_t bits = (uint32_t)((m0 >> src) & 1ull) | ((uint32_t)((m1 >> src) & 1ull) << 1) | ((uint32_t)((m2 >> src) & 1ull) << 2);
+                    int32_t Fb = Ps + __popc(bits & ((1u << comp) - 1u));        // flagged entries of the block below position idx
+                    acc[k] += idx <= 0 ? tot : (inside ? tot - Fb : 0);
+                } else {
+                    acc[k] += idx <= 0 ? tot : 0;
+                }
             }
         }
+        c0 = n0; c1 = n1;
     }
-    return d;
 }
 
 // ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
@@ -390,6 +415,7 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
                                                   int32_t *__restrict__ a_loc, int32_t *__restrict__ a_loc2,
                                                   int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2,
                                                   int64_t *__restrict__ a_taskR, const int64_t *__restrict__ a_tile_t0,
+                                                  const int4 *__restrict__ a_tile_rec,
                                                   const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR)
 {
     __shared__ int32_t s_off_all[4][LT + 2];
@@ -400,49 +426,31 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     bool active = tile_start < T;
     int32_t *s_off = s_off_all[wave];
     unsigned long long *s_hd = s_hd_all[wave];
-    int64_t t0 = active ? a_tile_t0[tile] : 0; int cnt = 0;
-    // interior tile: every step belongs to ONE task whose head lies in an earlier tile (four out of five tiles: the
-    // D&C re-scans the wide gaps of the arg-min staircase at every level).  Wave-uniform fast path: no task lookup, one
-    // threshold, plain scans, nothing to evaluate here (k_open finishes these tiles from `loc`).
-    bool interior = false;
-    int64_t toff0 = 0;
-    if (active) {
-        toff0 = a_offs[t0];
-        int64_t nx = a_offs[t0 + 1], tend = tile_start + LT < T ? tile_start + LT : T;
-        interior = toff0 < tile_start && nx >= tend;
+    // interior tile (k_tile_t0 classified it): four out of five tiles -- the D&C re-scans the wide gaps of the arg-min
+    // staircase at every level.  Wave-uniform fast path: nothing to look up, one threshold, nothing to evaluate here
+    // (k_open finishes these tiles from `loc`).
+    int4 rec = active ? a_tile_rec[tile] : make_int4(0, 0, 0, 0);
+    bool interior = rec.w != 0;
+    int64_t t0 = 0; int cnt = 0;
+    if (!interior) {
+        t0 = active ? a_tile_t0[tile] : 0;
+        load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     }
-    if (!interior) load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     __syncthreads();
     if (!active) return;
     if (interior) {
-        int4 td = a_tdesc[t0];
-        int32_t B = td.x, r = td.z;
-        int32_t rel = (int32_t)(tile_start - toff0);             // element index of the tile's first step (>= 1)
         int32_t tl = (T - tile_start < LT) ? (int32_t)(T - tile_start) - 1 : LT - 1;
-        int32_t carry = 0, carry2 = 0;
-        for (int g = 0; g < LT / 64; g++) {
-            int32_t e = g * 64 + lane;
-            bool valid = e <= tl;
-            int32_t p = B - (rel + e);
-            int32_t s = 0, en = 0, s2 = 0, en2 = 0;
-            if (valid) { s = a_pos[p]; en = a_pos[p + 1]; if (HYP) { s2 = a_fpos[p]; en2 = a_fpos[p + 1]; } }
-            int nvalid = tl - g * 64 + 1; nvalid = nvalid > 64 ? 64 : nvalid;
-            int32_t x = coop_count_run<true>(a_next, s, en, r, valid, lane, nvalid);
+        int32_t acc[4];
+        interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc);
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { int32_t pv = __shfl_up(x, o); if (lane >= o) x += pv; }
-            x += carry;
-            carry = __shfl(x, 63);
-            if (valid) a_loc[tile_start + e] = x;
-            if (HYP) {
-                int32_t x2 = coop_count_run<false>(a_flast, s2, en2, r, valid, lane, nvalid);
+        for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; if (e <= tl) a_loc[tile_start + e] = acc[k]; }
+        if (lane == (tl & 63)) a_tileS[tile] = (tl >> 6) == 0 ? acc[0] : (tl >> 6) == 1 ? acc[1] : (tl >> 6) == 2 ? acc[2] : acc[3];
+        if (HYP) {
+            interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc);
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { int32_t pv = __shfl_up(x2, o); if (lane >= o) x2 += pv; }
-                x2 += carry2;
-                carry2 = __shfl(x2, 63);
-                if (valid) a_loc2[tile_start + e] = x2;
-            }
+            for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; if (e <= tl) a_loc2[tile_start + e] = acc[k]; }
+            if (lane == (tl & 63)) a_tileS2[tile] = (tl >> 6) == 0 ? acc[0] : (tl >> 6) == 1 ? acc[1] : (tl >> 6) == 2 ? acc[2] : acc[3];
         }
-        if (lane == 0) { a_tileS[tile] = carry; if (HYP) a_tileS2[tile] = carry2; }
         return;
     }
     // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
@@ -732,6 +740,7 @@ struct LayerWork {
     DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
     DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
     DBuf<int32_t> open_list, fix_list, counts;          // tiles of long spans (k_span_short -> k_open / k_fix)
+    DBuf<int4> tile_rec;                                // {first column, row, -, interior?} per tile (k_tile_t0)
     int64_t max_tasks = 0;
 };
 
@@ -875,14 +884,15 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (Wk.tileS.n < (size_t)ntile) {
             Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
             Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
-            Wk.open_list.alloc((size_t)ntile); Wk.fix_list.alloc((size_t)ntile);
+            Wk.open_list.alloc((size_t)ntile); Wk.fix_list.alloc((size_t)ntile); Wk.tile_rec.alloc((size_t)ntile);
             if (!Wk.counts.p) Wk.counts.alloc(2);
             if (hyp) { Wk.tileS2.alloc((size_t)ntile); Wk.tilePS2.alloc((size_t)ntile + 1); }
         }
         if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         CP_HIP(hipMemsetAsync(Wk.counts.p, 0, 2 * sizeof(int32_t), s));
-        hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, Wk.tile_t0.p);
+        hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, T, Wk.tdesc.p, Wk.tile_t0.p,
+                           Wk.tile_rec.p);
         {
             // algorithmic bytes of one launch: per flattened step the stepped column's link
             // entries (4 B x N/n, plus 4 B x nonempty-rows/n for hyperedge costs), its colptr entry (8 B), the
@@ -890,7 +900,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * (avg_deg + self_deg) + 24.0));
 #define LP_ARGS R, T, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,           \
                 hyp ? A->flast.p : (const int32_t *)nullptr, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.loc.p, Wk.loc2.p, Wk.tileS.p, Wk.tileS2.p,     \
-                Wk.taskR.p, Wk.tile_t0.p, W, M, alpha
+                Wk.taskR.p, Wk.tile_t0.p, Wk.tile_rec.p, W, M, alpha
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, reinterpret_cast<Best<TC, false> *>(Wk.partR.p));
 #undef LP_ARGS
