@@ -98,6 +98,7 @@ def main():
                     help="connectivity = BASELINE config 3 (default, the metric); hyperedge = the config-5 cost "
                          "AffineHyperedgeCutModel(0,0,0,0,1) for scale checks")
     ap.add_argument("--dbg", type=int, default=0, help="timing experiments only (wrong results)")
+    ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (cp_set_option), e.g. short_t=4")
     ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
                     help="N>1: 'independent' = one partition per GPU (weak scaling, default); 'tiled' = ONE partition whose DP rows "
                          "are tiled over the GPUs with an RCCL all_gather per layer (strong scaling)")
@@ -131,6 +132,9 @@ def main():
     spl = np.zeros(K + 1, dtype=np.int64)
     if args.dbg:
         hip.set_option("dbg", args.dbg)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        assert hip.set_option(name, int(val)) == 0, kv
 
     def step():
         hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does

@@ -410,6 +410,8 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "force_brute")) { g_opt_force_brute = value; return CP_OK; }
     if (!strcmp(name, "brute_max_n")) { g_opt_brute_max_n = value; return CP_OK; }
     if (!strcmp(name, "dbg")) { g_opt_dbg = value; return CP_OK; }
+    if (!strcmp(name, "short_t")) { g_opt_short_t = value; return CP_OK; }
+    if (!strcmp(name, "short_e")) { g_opt_short_e = value; return CP_OK; }
     set_error("unknown option");
     return CP_EINVAL;
 }

@@ -30,6 +30,7 @@ int32_t run_seq_eval(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi,
 template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
+extern int64_t g_opt_short_t, g_opt_short_e;   // k_setup_short: tasks with <= short_t candidates and <= short_e link entries finish in setup
 extern int64_t g_opt_force_brute;      // cp_set_option("force_brute", 1)
 extern int64_t g_opt_brute_max_n;
 extern int64_t g_opt_dbg;            // timing experiments only (cp_set_option("dbg", mask)); results are wrong when non-zero      // largest n the O(n^2) path accepts

@@ -234,10 +234,92 @@ __device__ __forceinline__ void wave_segmin(Best<TC, HYP> &x, int &f, int lane)
     }
 }
 
+// ------------------------------------------------------------------ task setup, second form: short tasks finish here
+// One lane per task.  A task with at most `short_t` candidates and at most `short_e` link entries to step over is finished
+// by its lane on the spot (at low tau more than half of all tasks have ONE candidate: B == a, nothing to compare); the
+// rest are appended -- in order within a block -- to the list of long tasks that the flattened kernels below process.
+// (cp_set_option("short_t" / "short_e"): tunables, defaults chosen on config 3.)
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
+                                                      const int32_t *__restrict__ cr, const int32_t *__restrict__ crl,
+                                                      const int32_t *__restrict__ pos32, const int32_t *__restrict__ next,
+                                                      const int32_t *__restrict__ fpos32, const int32_t *__restrict__ flast,
+                                                      const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                      int4 *__restrict__ tdesc, uint8_t *__restrict__ tb, int32_t *__restrict__ len,
+                                                      int32_t *__restrict__ tS0l, int32_t *__restrict__ nlong, int32_t SHORT_T, int32_t SHORT_E)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    bool live = t < R.ntask;
+    bool is_long = false;
+    int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
+    if (live) {
+        decode_task(R, t, r, b);
+        int64_t n1 = R.n + 1;
+        if (R.isA) {
+            B = r; a = r - ((int64_t)1 << b);
+        } else {
+            int64_t rb = (r >> b) << b;
+            int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
+            B = opt[(int64_t)b * n1 + rL];
+            S0 = (int64_t)nnopt[(int64_t)b * n1 + rL] + cr[(int64_t)b * n1 + r];
+            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + rL] + crl[(int64_t)b * n1 + r];
+            a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
+            if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
+        }
+        int64_t L = 1 + (B - a);
+        bool is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
+        if (is_short) {
+            int64_t rw = (int64_t)b * n1 + r;
+            if (L == 1 && !R.isA) {                  // one candidate: nothing to compare
+                opt[rw] = (int32_t)B; nnopt[rw] = (int32_t)S0; if (HYP) nlopt[rw] = (int32_t)S0l;
+            } else {
+                int32_t rr = (int32_t)r, posr = pos32[r];
+                int64_t nn = S0, nl = S0l;
+                Best<TC, HYP> best; best_clear(best);
+                for (int64_t i = 0; i < L; i++) {    // decreasing p: an earlier candidate wins ties
+                    int64_t p = B - i;
+                    if (i > 0) {
+                        for (int32_t q = pos32[p]; q < pos32[p + 1]; q++) nn += (next[q] >= rr);
+                        if (HYP) for (int32_t q = fpos32[p]; q < fpos32[p + 1]; q++) nl += (flast[q] < rr);
+                    }
+                    if (i == 0 && R.isA) continue;   // round A: p = r is not a candidate
+                    TC fv = dm_apply(M, alpha, r - p, (int64_t)(posr - pos32[p]), nn, nl);
+                    Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
+                    best = better(best, c);
+                }
+                opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
+            }
+        } else {
+            is_long = true;
+        }
+    }
+    // append the long tasks: ONE atomic per 1024-lane block (same-address atomics serialise in L2), order kept inside the block
+    __shared__ int32_t s_wcnt[16];
+    __shared__ int32_t s_base;
+    unsigned long long ml = __ballot(is_long);
+    int wv = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[wv] = (int32_t)__popcll(ml);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < 16; w++) { int32_t c = s_wcnt[w]; s_wcnt[w] = tot; tot += c; }
+        s_base = tot ? atomicAdd(nlong, tot) : 0;
+    }
+    __syncthreads();
+    if (is_long) {
+        int32_t idx = s_base + s_wcnt[wv] + __popcll(ml & ((1ull << lane) - 1ull));
+        tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
+        tb[idx] = (uint8_t)b;
+        len[idx] = (int32_t)(1 + (B - a));
+        if (HYP) tS0l[idx] = (int32_t)S0l;
+    }
+}
+
 // ------------------------------------------------------------------ tile task table (one wave = one tile)
 // first task overlapping each tile: last t with offs[t] <= tile*LT (one thread per tile; offs[0] = 0)
 __global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ offs, int64_t ntask, int64_t ntile, int64_t T,
-                                                 const int4 *__restrict__ tdesc, int64_t *__restrict__ tile_t0, int4 *__restrict__ tile_rec)
+                                                 const int4 *__restrict__ tdesc, int64_t *__restrict__ tile_t0, int4 *__restrict__ tile_rec, int no_interior)
 {
     int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= ntile) return;
@@ -248,12 +330,12 @@ __global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ off
         if (offs[mid] <= tile_start) lo = mid; else hi = mid;
     }
     tile_t0[tile] = lo;
-    // interior tile: every step belongs to ONE task whose head lies in an earlier tile.  Record {first column, row, 0, 1}.
+    // interior tile: every step belongs to ONE task whose head lies in an earlier tile.  Record {first column, row, pos[row], 1}.
     int64_t toff = offs[lo], nx = offs[lo + 1], tend = tile_start + LT < T ? tile_start + LT : T;
     int4 rec = make_int4(0, 0, 0, 0);
-    if (toff < tile_start && nx >= tend) {
+    if (toff < tile_start && nx >= tend && !no_interior) {
         int4 td = tdesc[lo];
-        rec = make_int4(td.x - (int32_t)(tile_start - toff), td.z, 0, 1);
+        rec = make_int4(td.x - (int32_t)(tile_start - toff), td.z, td.w, 1);
     }
     tile_rec[tile] = rec;
 }
@@ -351,10 +433,9 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
 template <bool GE>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
-                                                int32_t thr, int lane, int32_t acc[4])
+                                                int32_t thr, int lane, int32_t acc[4], int32_t sk[4])
 {
     const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
-    int32_t sk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; sk[k] = e <= tl ? cpos[p_first - e] : INT32_MAX; acc[k] = 0; }
     int32_t Q_hi = cpos[p_first + 1], Q_lo = cpos[p_first - tl];              // wave-uniform
@@ -416,7 +497,8 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
                                                   int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2,
                                                   int64_t *__restrict__ a_taskR, const int64_t *__restrict__ a_tile_t0,
                                                   const int4 *__restrict__ a_tile_rec,
-                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR)
+                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ partR,
+                                                  Best<TC, HYP> *__restrict__ partL)
 {
     __shared__ int32_t s_off_all[4][LT + 2];
     __shared__ unsigned long long s_hd_all[4][LT / 64];
@@ -439,18 +521,37 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     __syncthreads();
     if (!active) return;
     if (interior) {
+        // The admitted costs are affine in the counts with constant coefficients, and all steps of the tile share the count
+        // made before the tile (the same task): the tile's arg-min does not depend on it.  Evaluate with the counts since
+        // the tile start; k_fix adds the task's base when it merges the tiles.
         int32_t tl = (T - tile_start < LT) ? (int32_t)(T - tile_start) - 1 : LT - 1;
-        int32_t acc[4];
-        interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; if (e <= tl) a_loc[tile_start + e] = acc[k]; }
-        if (lane == (tl & 63)) a_tileS[tile] = (tl >> 6) == 0 ? acc[0] : (tl >> 6) == 1 ? acc[1] : (tl >> 6) == 2 ? acc[2] : acc[3];
-        if (HYP) {
-            interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; if (e <= tl) a_loc2[tile_start + e] = acc[k]; }
-            if (lane == (tl & 63)) a_tileS2[tile] = (tl >> 6) == 0 ? acc[0] : (tl >> 6) == 1 ? acc[1] : (tl >> 6) == 2 ? acc[2] : acc[3];
+        int32_t acc[4], acc2[4] = {0, 0, 0, 0}, sk[4], sk2[4];
+        interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk);
+        if (HYP) interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc2, sk2);
+        int sel = tl >> 6;
+        if (lane == (tl & 63)) {
+            a_tileS[tile] = sel == 0 ? acc[0] : sel == 1 ? acc[1] : sel == 2 ? acc[2] : acc[3];
+            if (HYP) a_tileS2[tile] = sel == 0 ? acc2[0] : sel == 1 ? acc2[1] : sel == 2 ? acc2[2] : acc2[3];
         }
+        Best<TC, HYP> best; best_clear(best);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                       // increasing e = decreasing p: an earlier candidate wins ties
+            int32_t e = lane + 64 * k;
+            if (e <= tl) {
+                int32_t p = rec.x - e;
+                TC fv = dm_apply(M, alpha, (int64_t)(rec.y - p), (int64_t)(rec.z - sk[k]), (int64_t)acc[k], (int64_t)acc2[k]);
+                Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = p; c.nn = acc[k]; best_set_nl(c, acc2[k]);
+                best = better(best, c);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {                  // wave arg-min; ties -> larger p
+            int src = (lane + o) & 63;
+            Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
+            if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
+            bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
+            if (lane + o < 64 && take) best = c;
+        }
+        if (lane == 0) partL[tile] = best;
         return;
     }
     // local task index of a step = (#heads at or before it in the tile) - (1 if the tile starts with a head)
@@ -555,7 +656,8 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
                                                     const int32_t *__restrict__ a_tileS, const int32_t *__restrict__ a_tileS2,
                                                     const Best<TC, HYP> *__restrict__ partR, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                     int32_t *__restrict__ a_opt, int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
-                                                    int32_t *__restrict__ open_list, int32_t *__restrict__ fix_list, int32_t *__restrict__ counts)
+                                                    int32_t *__restrict__ open_list, int32_t *__restrict__ fix_list, int32_t *__restrict__ counts,
+                                                    const int4 *__restrict__ a_tile_rec)
 {
     int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -593,7 +695,7 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
     }
     // ---- role 2: this tile starts inside a task of a long span
     bool open_long = false;
-    if (in) {
+    if (in && a_tile_rec[tile].w == 0) {                   // interior tiles were evaluated by k_lpass
         int64_t tile_start = tile * LT;
         int64_t t0 = a_tile_t0[tile];
         int64_t toff0 = a_offs[t0];
@@ -672,7 +774,9 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
                                              const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
                                              const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
                                              int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
-                                             const int32_t *__restrict__ fix_list, const int32_t *__restrict__ counts)
+                                             const int32_t *__restrict__ fix_list, const int32_t *__restrict__ counts,
+                                             const int4 *__restrict__ tile_rec, const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2,
+                                             const int32_t *__restrict__ tS0l, DevModel<TC> M)
 {
     int lane = threadIdx.x & 63;
     int64_t nw = (int64_t)gridDim.x * 4;
@@ -681,9 +785,17 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
         int64_t tile = fix_list[w];
         int64_t t = taskR[tile];
         int64_t end_tile = (offs[t + 1] - 1) / LT;
+        int64_t S0 = tdesc[t].y, S0l = HYP ? (int64_t)tS0l[t] : 0;
         Best<TC, HYP> acc; best_clear(acc);
         for (int64_t k = tile + 1 + lane; k <= end_tile; k += 64) {
             Best<TC, HYP> c = partL[k];
+            if (tile_rec[k].w != 0 && c.p >= 0) {            // interior tile: counts and value are relative to the tile start
+                int64_t base = S0 + (tilePS[k] - tilePS[tile]);
+                int64_t base2 = HYP ? S0l + (tilePS2[k] - tilePS2[tile]) : 0;
+                c.v = cadd(c.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, base, base2));       // the costs are affine in the counts
+                c.nn = (int32_t)(c.nn + base);
+                if (HYP) best_set_nl(c, (int32_t)(best_nl(c) + base2));
+            }
             bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
             if (take) acc = c;
         }
@@ -863,12 +975,24 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
             if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
+        int32_t nlong = 0;
         {
+            // per task: four gathers from the plane arrays + the record; short tasks also step over their columns here
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
-            hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 0,
-                               Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr,
-                               hyp ? Wk.crl.p : (int32_t *)nullptr, hyp ? Wk.tS0l.p : (int32_t *)nullptr);
+            if (!Wk.counts.p) Wk.counts.alloc(4);
+            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, sizeof(int32_t), s));
+#define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
+                hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, Wk.counts.p + 2,               \
+                (int32_t)g_opt_short_t, (int32_t)g_opt_short_e
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
+#undef SS_ARGS
+            CP_HIP(hipMemcpyAsync(&nlong, Wk.counts.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            CP_HIP(hipStreamSynchronize(s));
         }
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d\n", R.isA, R.tau, (long long)R.ntask, nlong);
+        if (nlong <= 0) continue;
+        R.ntask = nlong;                            // from here on the round consists of the long tasks only
         {
             ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
             exclusive_scan_i32(Wk.len.p, Wk.offs.p, R.ntask, Wk.scratch, s);
@@ -885,14 +1009,13 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
             Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
             Wk.open_list.alloc((size_t)ntile); Wk.fix_list.alloc((size_t)ntile); Wk.tile_rec.alloc((size_t)ntile);
-            if (!Wk.counts.p) Wk.counts.alloc(2);
             if (hyp) { Wk.tileS2.alloc((size_t)ntile); Wk.tilePS2.alloc((size_t)ntile + 1); }
         }
         if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         CP_HIP(hipMemsetAsync(Wk.counts.p, 0, 2 * sizeof(int32_t), s));
         hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, T, Wk.tdesc.p, Wk.tile_t0.p,
-                           Wk.tile_rec.p);
+                           Wk.tile_rec.p, (int)((g_opt_dbg & 32) != 0));
         {
             // algorithmic bytes of one launch: per flattened step the stepped column's link
             // entries (4 B x N/n, plus 4 B x nonempty-rows/n for hyperedge costs), its colptr entry (8 B), the
@@ -901,8 +1024,9 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
 #define LP_ARGS R, T, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,           \
                 hyp ? A->flast.p : (const int32_t *)nullptr, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.loc.p, Wk.loc2.p, Wk.tileS.p, Wk.tileS2.p,     \
                 Wk.taskR.p, Wk.tile_t0.p, Wk.tile_rec.p, W, M, alpha
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, reinterpret_cast<Best<TC, false> *>(Wk.partR.p));
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p, Wk.partL.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS,
+                                        reinterpret_cast<Best<TC, false> *>(Wk.partR.p), reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
 #undef LP_ARGS
         }
         {
@@ -915,10 +1039,10 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             ProfScope ps(PROF_EVAL, s, 0.0);
 #define SP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.taskR.p, Wk.tileS.p, Wk.tileS2.p
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, true>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
-                               Wk.partR.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.open_list.p, Wk.fix_list.p, Wk.counts.p);
+                               Wk.partR.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.open_list.p, Wk.fix_list.p, Wk.counts.p, Wk.tile_rec.p);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, false>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partR.p), W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                               Wk.open_list.p, Wk.fix_list.p, Wk.counts.p);
+                               Wk.open_list.p, Wk.fix_list.p, Wk.counts.p, Wk.tile_rec.p);
 #undef SP_ARGS
             if (g_opt_dbg & 16) {
                 int32_t hc[2] = {0, 0};
@@ -936,10 +1060,12 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         {
             ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
-                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.fix_list.p, Wk.counts.p);
+                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.fix_list.p, Wk.counts.p,
+                               Wk.tile_rec.p, Wk.tilePS.p, Wk.tilePS2.p, Wk.tS0l.p, M);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
-                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.fix_list.p, Wk.counts.p);
+                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.fix_list.p, Wk.counts.p,
+                               Wk.tile_rec.p, Wk.tilePS.p, (const int64_t *)nullptr, (const int32_t *)nullptr, M);
         }
         CP_HIP(hipGetLastError());
     }
