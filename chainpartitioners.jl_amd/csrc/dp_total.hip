@@ -670,7 +670,8 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
         if (t >= 0) {
             int64_t end = a_offs[t + 1] - 1, ntl = (tile + 1) * LT;
             int64_t open_len = end - ntl + 1;
-            if (end / LT == tile + 1 && open_len <= SPAN_SHORT) {
+            // (a partial last tile can be both "fully covered" = interior, evaluated by k_lpass, and short: interior wins)
+            if (end / LT == tile + 1 && open_len <= SPAN_SHORT && a_tile_rec[tile + 1].w == 0) {
                 int4 td = a_tdesc[t];
                 int64_t toff = a_offs[t];
                 int64_t B = td.x, r = td.z;
@@ -1014,6 +1015,15 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
         CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
         CP_HIP(hipMemsetAsync(Wk.counts.p, 0, 2 * sizeof(int32_t), s));
+        if (g_opt_dbg & 128) {                    // poison everything a round must write before it reads
+            int pat = (g_opt_dbg & 256) ? 0x00 : 0x7F;
+            CP_HIP(hipMemsetAsync(Wk.loc.p, pat, sizeof(int32_t) * (size_t)T, s));
+            if (hyp) CP_HIP(hipMemsetAsync(Wk.loc2.p, pat, sizeof(int32_t) * (size_t)T, s));
+            CP_HIP(hipMemsetAsync(Wk.partL.p, pat, Wk.partL.bytes(), s));
+            CP_HIP(hipMemsetAsync(Wk.partR.p, pat, Wk.partR.bytes(), s));
+            CP_HIP(hipMemsetAsync(Wk.tileS.p, pat, sizeof(int32_t) * (size_t)ntile, s));
+            if (hyp) CP_HIP(hipMemsetAsync(Wk.tileS2.p, pat, sizeof(int32_t) * (size_t)ntile, s));
+        }
         hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, T, Wk.tdesc.p, Wk.tile_t0.p,
                            Wk.tile_rec.p, (int)((g_opt_dbg & 32) != 0));
         {

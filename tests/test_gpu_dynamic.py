@@ -104,3 +104,29 @@ def test_objective_and_bounds(hip, orc):
                     assert f(A, Phi, mdl, backend=hip) == f(A, Phi, mdl, backend=orc)
             for mdl in (cp.AffineWorkModel(0, 10, 1), cp.AffineConnectivityModel(0, 10, 1, 100)):
                 assert cp.bound_stripe(A, K, mdl, backend=hip) == cp.bound_stripe(A, K, mdl, backend=orc)
+
+
+def test_no_read_before_write_in_round_buffers(hip, orc):
+    """The per-round work buffers (step counts, tile partials) are recycled allocations: poison them before every round
+    (cp_set_option("dbg", 128 [+256]): all-0x7F / all-zero bytes) and demand identical tables -- a kernel that read a
+    cell another kernel was supposed to write shows up as a mismatch for one of the two patterns."""
+    A = banded(777, 4, 0.5, 9)
+    B = suitesparse_shaped(3000, 6, 5)
+    for mdl in (MODELS[0], MODELS[1], MODELS[6]):
+        mm = mdl.marshal()
+        for M_ in (A, B):
+            rc2, p2, c2 = orc.dynamic_tables(M_, 5, 0, mm, None)
+            for dbg in (128, 128 + 256, 0):
+                hip.set_option("dbg", dbg)
+                try:
+                    rc1, p1, c1 = hip.dynamic_tables(M_, 5, 0, mm, None)
+                finally:
+                    hip.set_option("dbg", 0)
+                assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), (dbg, M_)
+            for (st, se) in ((0, 0), (1, 64), (100, 100000)):
+                hip.set_option("short_t", st); hip.set_option("short_e", se)
+                try:
+                    rc1, p1, c1 = hip.dynamic_tables(M_, 5, 0, mm, None)
+                finally:
+                    hip.set_option("short_t", 4); hip.set_option("short_e", 64)
+                assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, M_)
