@@ -196,7 +196,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC counters: collected by tools/pmc_lpass.sh under rocprofv3
         # (FETCH_SIZE and WRITE_SIZE in separate passes) and committed under profiles/; valid for the default workload only
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_lpass.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc_k_lpass.json")
         if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
             traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
         out = {
