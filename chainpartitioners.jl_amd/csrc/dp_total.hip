@@ -32,6 +32,16 @@ namespace cpk {
 constexpr int LT = 256;          // steps per tile (one wave owns one tile)
 constexpr int NBMAX = 31;        // bit planes (n < 2^30)
 
+// Plane arrays (opt / nnopt / nlopt / cr / crl) hold row r of a bit plane at slot prow(r): rows are grouped by their level
+// ctz(r) -- the rows one round reads and writes are then CONTIGUOUS in every plane (in row-major order they sit 2^(tau+1)
+// entries apart and every round drags whole planes through HBM).  #rows in [1, n] with ctz < t is n - (n >> t).
+__device__ __forceinline__ int64_t prow(int64_t r, int64_t n)
+{
+    int t = __ffsll((long long)r) - 1;
+    return (n - (n >> t)) + (r >> (t + 1));
+}
+#define PR(x) prow((x), n1 - 1)
+
 struct RoundDesc {
     int32_t isA, tau, nbits, nextra;
     int64_t n, ntask;
@@ -58,38 +68,52 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 // Small ranges: one lane per row (tau <= 3).
 // `ge` selects the comparison: 0: link < threshold (nets: prev[q] < B); 1: link >= threshold (self nets: first >= B
 // over the rows bucketed by their LAST column).
+// The 64 rows of a wave are consecutive, so they share every bit above tau + 6: planes whose bit is clear in the whole
+// wave are skipped with a wave-uniform test (about half of them).
+// (Tried: deciding all planes but one by the position of the link value among the Fenwick blocks, with lane-private LDS
+//  histograms -- 4x fewer VALU instructions but 300 B of LDS per row leave 2 waves per SIMD: slower.)
 template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
                                                      int32_t *__restrict__ cr)
 {
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nrows) return;
+    bool live = u < nrows;
     u += u0;
     int64_t r = ((u << 1) | 1) << tau;
-    if (r > n) return;
+    if (r > n) live = false;
+    if (!live) r = 0;                                          // no bits: takes part in the ballots only
     int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
     int32_t thr[NBMAX], cnt[NBMAX];
+    uint32_t used = 0;                                         // planes with a set bit somewhere in the wave (uniform)
+    int64_t prL = live ? PR(rL) : 0;
+    // all threshold loads are issued back to back (a lane without bit b reads a valid dummy slot): one memory latency, not 23
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
-        bool on = b > tau && b < nbits && ((r >> b) & 1);
-        thr[b] = on ? opt[(int64_t)b * n1 + rL] : (ge ? INT32_MAX : INT32_MIN);
         cnt[b] = 0;
+        thr[b] = ge ? INT32_MAX : INT32_MIN;
+        if (b <= tau || b >= nbits) continue;                  // wave-uniform
+        bool on = (r >> b) & 1;
+        if (!__ballot(on)) continue;                           // wave-uniform
+        used |= 1u << b;
+        int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
+        if (on) thr[b] = v;
     }
+    if (!live) return;
     int64_t q0 = pos[rL], q1 = pos[r];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
     for (int64_t q = q0; q < q1; q += 4) {                     // four independent loads in flight per lane
         int32_t v0 = prev[q], v1 = q + 1 < q1 ? prev[q + 1] : NEVER, v2 = q + 2 < q1 ? prev[q + 2] : NEVER, v3 = q + 3 < q1 ? prev[q + 3] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
-            if (b <= tau || b >= nbits) continue;              // wave-uniform
+            if (!((used >> b) & 1)) continue;                  // wave-uniform
             int32_t t = thr[b];
             cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
         }
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++)
-        if (b > tau && b < nbits && ((r >> b) & 1)) cr[(int64_t)b * n1 + r] = cnt[b];
+        if (b > tau && b < nbits && ((r >> b) & 1)) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
 }
 
 // Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
@@ -110,11 +134,15 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     int64_t c0 = rL + (int64_t)ck * ch_cols, c1 = c0 + ch_cols;
     if (c1 > r) c1 = r;
     int32_t thr[NBMAX], cnt[NBMAX];
+    int64_t prL = PR(rL);
 #pragma unroll
-    for (int b = 0; b < NBMAX; b++) {
-        bool on = b > tau && b < nbits && ((r >> b) & 1);
-        thr[b] = on ? opt[(int64_t)b * n1 + rL] : (ge ? INT32_MAX : INT32_MIN);       // wave-uniform address
+    for (int b = 0; b < NBMAX; b++) {                          // loads issued back to back; addresses are wave-uniform
         cnt[b] = 0;
+        thr[b] = ge ? INT32_MAX : INT32_MIN;
+        if (b <= tau || b >= nbits) continue;
+        bool on = (r >> b) & 1;
+        int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
+        if (on) thr[b] = v;
     }
     int64_t q0 = pos[c0], q1 = pos[c1];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
@@ -135,8 +163,8 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
             int32_t c = cnt[b];
             for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
             if (lane == 0) {
-                if (chunks_per_row == 1) cr[(int64_t)b * n1 + r] = c;
-                else atomicAdd(&cr[(int64_t)b * n1 + r], c);
+                if (chunks_per_row == 1) cr[(int64_t)b * n1 + PR(r)] = c;
+                else atomicAdd(&cr[(int64_t)b * n1 + PR(r)], c);
             }
         }
     }
@@ -156,17 +184,17 @@ __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__res
     int64_t r; int b;
     decode_task(R, t, r, b);
     int64_t n1 = R.n + 1;
-    if (zero_cr_only) { cr[(int64_t)b * n1 + r] = 0; if (crl) crl[(int64_t)b * n1 + r] = 0; return; }
+    if (zero_cr_only) { cr[(int64_t)b * n1 + PR(r)] = 0; if (crl) crl[(int64_t)b * n1 + PR(r)] = 0; return; }
     int64_t B, a, S0, S0l = 0;
     if (R.isA) {
         B = r; a = r - ((int64_t)1 << b); S0 = 0;
     } else {
         int64_t rb = (r >> b) << b;
         int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
-        B = opt[(int64_t)b * n1 + rL];
-        S0 = (int64_t)nnopt[(int64_t)b * n1 + rL] + cr[(int64_t)b * n1 + r];
-        if (tS0l) S0l = (int64_t)nlopt[(int64_t)b * n1 + rL] + crl[(int64_t)b * n1 + r];
-        a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
+        B = opt[(int64_t)b * n1 + PR(rL)];
+        S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
+        if (tS0l) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
+        a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + PR(rR)] : rb - ((int64_t)1 << b);
         if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
     }
     tdesc[t] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);      // one 16-byte record per task
@@ -261,16 +289,16 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         } else {
             int64_t rb = (r >> b) << b;
             int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
-            B = opt[(int64_t)b * n1 + rL];
-            S0 = (int64_t)nnopt[(int64_t)b * n1 + rL] + cr[(int64_t)b * n1 + r];
-            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + rL] + crl[(int64_t)b * n1 + r];
-            a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + rR] : rb - ((int64_t)1 << b);
+            B = opt[(int64_t)b * n1 + PR(rL)];
+            S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
+            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
+            a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + PR(rR)] : rb - ((int64_t)1 << b);
             if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
         }
         int64_t L = 1 + (B - a);
         bool is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
         if (is_short) {
-            int64_t rw = (int64_t)b * n1 + r;
+            int64_t rw = (int64_t)b * n1 + PR(r);
             if (L == 1 && !R.isA) {                  // one candidate: nothing to compare
                 opt[rw] = (int32_t)B; nnopt[rw] = (int32_t)S0; if (HYP) nlopt[rw] = (int32_t)S0l;
             } else {
@@ -627,9 +655,9 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
         if (head_in_tile) {
             if (e == seg_last) {
                 int b = a_tb[t];
-                a_opt[(int64_t)b * n1 + r] = bx.p;
-                a_nnopt[(int64_t)b * n1 + r] = bx.nn;
-                if (HYP) a_nlopt[(int64_t)b * n1 + r] = best_nl(bx);
+                a_opt[(int64_t)b * n1 + PR(r)] = bx.p;
+                a_nnopt[(int64_t)b * n1 + PR(r)] = bx.nn;
+                if (HYP) a_nlopt[(int64_t)b * n1 + PR(r)] = best_nl(bx);
             } else if (e == tile_last) {
                 partR[tile] = bx; a_taskR[tile] = (int64_t)t;
             }
@@ -686,9 +714,9 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
                     best = better(best, c);
                 }
                 int b = a_tb[t];
-                a_opt[(int64_t)b * n1 + r] = best.p;
-                a_nnopt[(int64_t)b * n1 + r] = best.nn;
-                if (HYP) a_nlopt[(int64_t)b * n1 + r] = best_nl(best);
+                a_opt[(int64_t)b * n1 + PR(r)] = best.p;
+                a_nnopt[(int64_t)b * n1 + PR(r)] = best.nn;
+                if (HYP) a_nlopt[(int64_t)b * n1 + PR(r)] = best_nl(best);
             } else {
                 fix_long = true;
             }
@@ -810,9 +838,9 @@ __global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__res
         if (lane == 0) {
             Best<TC, HYP> res = better(partR[tile], acc);   // the head tile holds the larger p: wins ties
             int64_t r = tdesc[t].z; int b = tb[t];
-            opt[(int64_t)b * n1 + r] = res.p;
-            nnopt[(int64_t)b * n1 + r] = res.nn;
-            if (HYP) nlopt[(int64_t)b * n1 + r] = best_nl(res);
+            opt[(int64_t)b * n1 + PR(r)] = res.p;
+            nnopt[(int64_t)b * n1 + PR(r)] = res.nn;
+            if (HYP) nlopt[(int64_t)b * n1 + PR(r)] = best_nl(res);
         }
     }
 }
@@ -832,9 +860,9 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t
     int64_t bp = r;
     for (int b = 0; b < nbits; b++) {
         if (!((r >> b) & 1)) continue;
-        int64_t p = opt[(int64_t)b * n1 + r];
-        int64_t nn = nnopt[(int64_t)b * n1 + r];
-        int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + r] : 0;
+        int64_t p = opt[(int64_t)b * n1 + PR(r)];
+        int64_t nn = nnopt[(int64_t)b * n1 + PR(r)];
+        int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + PR(r)] : 0;
         TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, nl));
         if (v < bv) { bv = v; bp = p; }            // lower bits hold larger p: strict < keeps the largest p on ties
     }
