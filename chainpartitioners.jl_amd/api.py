@@ -78,21 +78,27 @@ def _rowpart(Pi, need_spl=False):
     return rp, keep
 
 
-def _w_table_for(A, f, weight, w_max):
-    """Tabulation length for closures: widths never exceed the constraint, else n."""
+def _w_table_for(A, f, weight, w_max, stack_method=False):
+    """Tabulation range (lo, hi) of closures over the part width.  DP methods only evaluate feasible pairs: 0 .. w_max under a
+    VertexCount constraint, else 0 .. n.  The Convex/Concave chunkers (stack_method) also evaluate pairs outside the
+    constraint and -- when the cost is not convex and their candidate stack goes stale -- pairs with j > j' inside one
+    feasible window (ConvexTotalChunker.jl:76,99): widths -(w_max+1) .. 2(w_max+1) under VertexCount, -n .. n otherwise."""
     if weight is not None and isinstance(weight, M.VertexCount):
-        return int(w_max) + 1
-    return A.n + 1
+        w = int(w_max)
+        return (-(2 * w + 2), 2 * w + 3) if stack_method else (0, w + 1)
+    return (-(A.n + 1), A.n + 1) if stack_method else (0, A.n + 1)
 
 
-def _marshal(A, f, Pi):
+def _marshal(A, f, Pi, stack_method=False):
     mdl, weight, w_max = M.split_constraint(f)
-    wt = _w_table_for(A, mdl, weight, w_max)
+    wlo, wt = _w_table_for(A, mdl, weight, w_max, stack_method)
+    if not isinstance(mdl, (M.BlockComponentCostModel, M.ColumnBlockComponentCostModel)):
+        wlo = 0
     if isinstance(mdl, M.BlockComponentCostModel):
         ut = A.m + 1
-        mm = mdl.marshal(w_table=wt) if mdl.u_table is not None else _marshal_block(mdl, wt, ut)
+        mm = mdl.marshal(w_table=wt, w_lo=wlo) if mdl.u_table is not None else _marshal_block(mdl, wt, ut, wlo)
     else:
-        mm = mdl.marshal(w_table=wt)
+        mm = mdl.marshal(w_table=wt, w_lo=wlo)
     wm = weight.marshal() if weight is not None else None
     wmax_i = int(w_max) if weight is not None and (weight.dtype == M.CP_I64) else 0
     wmax_f = float(w_max) if weight is not None else 0.0
@@ -100,11 +106,11 @@ def _marshal(A, f, Pi):
     return mdl, mm, wm, wmax_i, wmax_f, rp, keep
 
 
-def _marshal_block(mdl, wt, ut):
+def _marshal_block(mdl, wt, ut, wlo=0):
     old = (mdl.w_table, mdl.u_table)
     mdl.w_table, mdl.u_table = wt, ut
     try:
-        return mdl.marshal()
+        return mdl.marshal(w_lo=wlo)
     finally:
         mdl.w_table, mdl.u_table = old
 
@@ -150,13 +156,13 @@ def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) ->
         _check(rc, "partition_stripe(LazyBisectCost)", b)
         return SplitPartition(K, spl)
     if isinstance(method, M.ConvexTotalSplitter):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi, stack_method=True)
         spl = np.zeros(K + 1, dtype=np.int64)
         rc = b.partition_convex(A, K, mm, rp, wm, wi, wf, spl)
         _check(rc, "partition_stripe(ConvexTotalSplitter)", b)
         return SplitPartition(K, spl)
     if isinstance(method, M.ConcaveTotalSplitter):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi, stack_method=True)
         spl = np.zeros(K + 1, dtype=np.int64)
         rc = b.partition_concave(A, K, mm, rp, wm, wi, wf, spl)
         _check(rc, "partition_stripe(ConcaveTotalSplitter)", b)
@@ -179,14 +185,14 @@ def pack_stripe(A: SparseMatrixCSC, method, Pi=None, *, backend=None) -> SplitPa
         _check(rc, "pack_stripe(DynamicTotalChunker)", b)
         return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
     if isinstance(method, M.ConvexTotalChunker):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi, stack_method=True)
         spl = np.zeros(A.n + 1, dtype=np.int64)
         Kout = np.zeros(1, dtype=np.int64)
         rc = b.pack_convex(A, mm, rp, wm, wi, wf, spl, Kout)
         _check(rc, "pack_stripe(ConvexTotalChunker)", b)
         return SplitPartition(int(Kout[0]), spl[:int(Kout[0]) + 1].copy())
     if isinstance(method, M.ConcaveTotalChunker):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi, stack_method=True)
         spl = np.zeros(A.n + 1, dtype=np.int64)
         Kout = np.zeros(1, dtype=np.int64)
         rc = b.pack_concave(A, mm, rp, wm, wi, wf, spl, Kout)

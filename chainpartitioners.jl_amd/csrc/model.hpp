@@ -42,6 +42,7 @@ struct DevModel {
     TC ac_c, bc_c[CP_MAX_R];
     const TC *ac_tab, *bc_tab[CP_MAX_R];
     int64_t ac_len, bc_len[CP_MAX_R];
+    int64_t ac_lo, bc_lo[CP_MAX_R];       // width of table entry 0
     int32_t R;
 };
 
@@ -53,11 +54,12 @@ __host__ __device__ __forceinline__ TC dm_alpha(const DevModel<TC> &m, int64_t k
 }
 
 template <typename TC>
-__device__ __forceinline__ TC dm_comp(int32_t is_const, TC c, const TC *tab, int64_t len, int64_t w)
+__device__ __forceinline__ TC dm_comp(int32_t is_const, TC c, const TC *tab, int64_t len, int64_t lo, int64_t w)
 {
     if (is_const) return c;
+    w -= lo;
     if (w < 0) w = 0;
-    if (w >= len) w = len - 1;     // host validates table lengths before launch
+    if (w >= len) w = len - 1;     // the host mirror sizes the tables for every width a method can evaluate
     return tab[w];
 }
 
@@ -83,8 +85,8 @@ __device__ __forceinline__ TC dm_apply(const DevModel<TC> &m, TC alpha, int64_t 
         return cadd(cadd(cadd(cadd(alpha, cmulc(nv, m.p[CP_P_VERTEX])), cmulc(np, m.p[CP_P_PIN])),
                          cmulc(nl, m.p[CP_P_SELF_NET])), cmulc(nn - nl, m.p[CP_P_CUT_NET]));
     case CP_MODEL_COLBLOCK:
-        return cadd(dm_comp(m.ac_const, m.ac_c, m.ac_tab, m.ac_len, nv),
-                    cmulc(nn, dm_comp(m.bc_const[0], m.bc_c[0], m.bc_tab[0], m.bc_len[0], nv)));
+        return cadd(dm_comp(m.ac_const, m.ac_c, m.ac_tab, m.ac_len, m.ac_lo, nv),
+                    cmulc(nn, dm_comp(m.bc_const[0], m.bc_c[0], m.bc_tab[0], m.bc_len[0], m.bc_lo[0], nv)));
     case CP_MODEL_VERTEX_COUNT:
         return (TC)nv;
     case CP_MODEL_POWER_WORK:
@@ -140,10 +142,10 @@ void build_dev_model(const cp_model_t *m, HostModel<TC> &H, hipStream_t s)
         H.d.n_alpha_k = m->n_alpha_k;
     }
     H.d.R = m->R;
-    auto up = [&](const cp_component_t &c, int slot, int32_t &is_c, TC &cc, const TC *&tab, int64_t &len) {
+    auto up = [&](const cp_component_t &c, int slot, int32_t &is_c, TC &cc, const TC *&tab, int64_t &len, int64_t &lo) {
         is_c = c.is_const;
         cc = comp_const<TC>(c);
-        tab = nullptr; len = 0;
+        tab = nullptr; len = 0; lo = c.lo;
         if (!c.is_const && c.table && c.len > 0) {
             H.tabs[slot].alloc((size_t)c.len);
             CP_HIP(hipMemcpyAsync(H.tabs[slot].p, c.table, sizeof(TC) * (size_t)c.len, hipMemcpyHostToDevice, s));
@@ -151,9 +153,9 @@ void build_dev_model(const cp_model_t *m, HostModel<TC> &H, hipStream_t s)
         }
     };
     if (m->kind == CP_MODEL_COLBLOCK || m->kind == CP_MODEL_BLOCK) {
-        up(m->alpha_col, 0, H.d.ac_const, H.d.ac_c, H.d.ac_tab, H.d.ac_len);
+        up(m->alpha_col, 0, H.d.ac_const, H.d.ac_c, H.d.ac_tab, H.d.ac_len, H.d.ac_lo);
         for (int r = 0; r < m->R && r < CP_MAX_R; r++)
-            up(m->beta_col[r], 1 + r, H.d.bc_const[r], H.d.bc_c[r], H.d.bc_tab[r], H.d.bc_len[r]);
+            up(m->beta_col[r], 1 + r, H.d.bc_const[r], H.d.bc_c[r], H.d.bc_tab[r], H.d.bc_len[r], H.d.bc_lo[r]);
     }
 }
 

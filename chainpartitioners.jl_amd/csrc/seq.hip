@@ -41,7 +41,7 @@ struct SeqOracle {
     // optional table of every pair inside a width window: Ftab[j' * (Wc+1) + (j'-j)] = f(j, j') for j'-j <= Wc
     const TC *Ftab; int64_t Wc;
     // block-row components
-    int32_t br_const[CP_MAX_R]; TC br_c[CP_MAX_R]; const TC *br_tab[CP_MAX_R]; int64_t br_len[CP_MAX_R];
+    int32_t br_const[CP_MAX_R]; TC br_c[CP_MAX_R]; const TC *br_tab[CP_MAX_R]; int64_t br_len[CP_MAX_R], br_lo[CP_MAX_R];
 };
 
 template <typename TC>
@@ -66,11 +66,11 @@ __device__ TC block_call(const SeqOracle<TC> &O, int64_t j, int64_t jp)
             int64_t j0 = O.hst[k - 1] - 1;
             int64_t u = O.P_spl[k] - O.P_spl[k - 1];
             if (j0 < ojp) {
-                for (int r = 1; r <= R; r++) DL(r, j0 + 1) = cadd(DL(r, j0 + 1), (TC)0 - dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
-                for (int r = 1; r <= R; r++) DL(r, ojp + 1) = cadd(DL(r, ojp + 1), dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
+                for (int r = 1; r <= R; r++) DL(r, j0 + 1) = cadd(DL(r, j0 + 1), (TC)0 - dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], O.br_lo[r - 1], u));
+                for (int r = 1; r <= R; r++) DL(r, ojp + 1) = cadd(DL(r, ojp + 1), dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], O.br_lo[r - 1], u));
             }
             if (j0 < oj)
-                for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], u));
+                for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], dm_comp(O.br_const[r - 1], O.br_c[r - 1], O.br_tab[r - 1], O.br_len[r - 1], O.br_lo[r - 1], u));
             O.hst[k - 1] = ojp + 1;
         }
         ojp += 1;
@@ -79,8 +79,8 @@ __device__ TC block_call(const SeqOracle<TC> &O, int64_t j, int64_t jp)
     while (j > oj) { for (int r = 1; r <= R; r++) d[r - 1] = cadd(d[r - 1], (TC)0 - DL(r, oj + 1)); oj += 1; }
 #undef DL
     int64_t w = jp - j;
-    TC c = dm_comp(f.ac_const, f.ac_c, f.ac_tab, f.ac_len, w);
-    for (int r = 1; r <= R; r++) c = cadd(c, cmulv(d[r - 1], dm_comp(f.bc_const[r - 1], f.bc_c[r - 1], f.bc_tab[r - 1], f.bc_len[r - 1], w)));
+    TC c = dm_comp(f.ac_const, f.ac_c, f.ac_tab, f.ac_len, f.ac_lo, w);
+    for (int r = 1; r <= R; r++) c = cadd(c, cmulv(d[r - 1], dm_comp(f.bc_const[r - 1], f.bc_c[r - 1], f.bc_tab[r - 1], f.bc_len[r - 1], f.bc_lo[r - 1], w)));
     O.cursor[0] = oj; O.cursor[1] = ojp;
     return c;
 }
@@ -89,7 +89,7 @@ template <typename TC>
 __device__ TC ocl(const SeqOracle<TC> &O, int64_t j, int64_t jp, int64_t k)
 {
     if (O.M.kind == CP_MODEL_BLOCK) return block_call(O, j, jp);
-    if (O.Ftab && jp - j <= O.Wc) return O.Ftab[jp * (O.Wc + 1) + (jp - j)];
+    if (O.Ftab && jp >= j && jp - j <= O.Wc) return O.Ftab[jp * (O.Wc + 1) + (jp - j)];     // (j > j' happens: see cp_component_t)
     int64_t p = j - 1, r = jp - 1;
     int64_t np = O.pos[r] - O.pos[p];
     int64_t nn = 0, nl = 0;
@@ -633,7 +633,7 @@ static void seq_oracle(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *P
         C.O.P_asg = C.asg.p; C.O.P_spl = C.pspl.p; C.O.Kr = K; C.O.hst = C.hst.p; C.O.Delta = C.Delta.p; C.O.d = C.dvec.p; C.O.cursor = C.cursor.p;
         for (int r = 0; r < mdl->R && r < CP_MAX_R; r++) {
             const cp_component_t &c = mdl->beta_row[r];
-            C.O.br_const[r] = c.is_const; C.O.br_c[r] = comp_const<TC>(c); C.O.br_tab[r] = nullptr; C.O.br_len[r] = 0;
+            C.O.br_const[r] = c.is_const; C.O.br_c[r] = comp_const<TC>(c); C.O.br_tab[r] = nullptr; C.O.br_len[r] = 0; C.O.br_lo[r] = c.lo;
             if (!c.is_const && c.table && c.len > 0) {
                 C.brtab[r].alloc((size_t)c.len);
                 CP_HIP(hipMemcpyAsync(C.brtab[r].p, c.table, sizeof(TC) * (size_t)c.len, hipMemcpyHostToDevice, s));

@@ -35,7 +35,7 @@ CP_OK, CP_EINVAL, CP_INFEASIBLE, CP_EHIP, CP_EUNSUPPORTED = range(5)
 
 class cp_component_t(C.Structure):
     _fields_ = [("is_const", C.c_int32), ("_pad", C.c_int32), ("c_i64", C.c_int64), ("c_f64", C.c_double),
-                ("table", C.c_void_p), ("len", C.c_int64)]
+                ("table", C.c_void_p), ("len", C.c_int64), ("lo", C.c_int64)]
 
 
 class cp_model_t(C.Structure):
@@ -90,8 +90,9 @@ class _Model:
     def _alpha_k(self):
         return None
 
-    def marshal(self, w_table=None):
+    def marshal(self, w_table=None, w_lo=0):
         s = cp_model_t()
+        self._w_lo = w_lo
         keep = []
         s.kind = self.kind
         s.dtype = self.dtype
@@ -204,14 +205,28 @@ class AffineHyperedgeCutModel(_Model):
                 + n_self * self.beta_self_net + n_cut * self.beta_cut_net)
 
 
-def _component(f, dtype, w_table, keep):
-    """block_component(f, w) (BlockCosts.jl:41-44): number | callable | tuple/array (1-based)."""
+def _tabulate(f, lo, hi, npdt):
+    """f(w) for w = lo .. hi; vectorised when the callable allows it, checked against three scalar calls."""
+    ws = np.arange(lo, hi + 1, dtype=np.int64)
+    try:
+        tab = np.asarray(f(ws))
+        if tab.shape == ws.shape and all(tab[i] == f(int(ws[i])) for i in (0, len(ws) // 2, len(ws) - 1)):
+            return tab.astype(npdt)
+    except Exception:
+        pass
+    return np.array([f(int(w)) for w in ws], dtype=npdt)
+
+
+def _component(f, dtype, w_table, keep, w_lo=0):
+    """block_component(f, w) (BlockCosts.jl:41-44): number | callable | tuple/array (1-based).
+    Callables are tabulated for w = w_lo .. w_table (w_lo < 0: see cp_component_t in include/chainpart_types.h)."""
     c = cp_component_t()
     npdt = np.int64 if dtype == CP_I64 else np.float64
     if callable(f):
         if w_table is None:
             raise ValueError("a callable block component needs w_table (tabulation length)")
-        tab = np.array([f(w) for w in range(0, w_table + 1)], dtype=npdt)
+        tab = _tabulate(f, w_lo, w_table, npdt)
+        c.lo = int(w_lo)
     elif isinstance(f, (list, tuple, np.ndarray)):
         arr = np.asarray(f)
         tab = np.concatenate([[0], arr]).astype(npdt)   # Julia f[w], w >= 1
@@ -242,8 +257,8 @@ class ColumnBlockComponentCostModel(_Model):
     def _marshal_extra(self, s, keep, w_table):
         wt = w_table if w_table is not None else self.w_table
         s.R = 1
-        s.alpha_col = _component(self.alpha_col, self.dtype, wt, keep)
-        s.beta_col[0] = _component(self.beta_col, self.dtype, wt, keep)
+        s.alpha_col = _component(self.alpha_col, self.dtype, wt, keep, getattr(self, "_w_lo", 0))
+        s.beta_col[0] = _component(self.beta_col, self.dtype, wt, keep, getattr(self, "_w_lo", 0))
 
     def __call__(self, n_vertices, n_pins, n_nets, k=None):
         bc = lambda f, w: f(w) if callable(f) else (f[w - 1] if isinstance(f, (list, tuple, np.ndarray)) else f)
@@ -266,10 +281,11 @@ class BlockComponentCostModel(_Model):
         ut = self.u_table if self.u_table is not None else wt
         s.R = len(self.beta_row)
         s.alpha_row = _component(self.alpha_row, self.dtype, ut, keep)
-        s.alpha_col = _component(self.alpha_col, self.dtype, wt, keep)
+        lo = getattr(self, "_w_lo", 0)
+        s.alpha_col = _component(self.alpha_col, self.dtype, wt, keep, lo)
         for r in range(s.R):
             s.beta_row[r] = _component(self.beta_row[r], self.dtype, ut, keep)
-            s.beta_col[r] = _component(self.beta_col[r], self.dtype, wt, keep)
+            s.beta_col[r] = _component(self.beta_col[r], self.dtype, wt, keep, lo)
 
 
 class VertexCount(_Model):

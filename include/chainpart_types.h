@@ -61,14 +61,17 @@ extern "C" {
 #define CP_MAX_R 4
 
 /* block_component(f, w) (BlockCosts.jl:41-44): a number, or a closure/tuple/array
- * that the host tabulates for w = 0 .. len-1 (closures cannot cross a C ABI). */
+ * that the host tabulates for w = lo .. lo+len-1 (closures cannot cross a C ABI).  lo < 0 is needed by the
+ * Convex/Concave chunkers: on a cost that is not convex their candidate stack goes stale and they evaluate f(j, j')
+ * with j > j' (ConvexTotalChunker.jl:76, :99), i.e. the closure at a negative width. */
 typedef struct cp_component {
-    int32_t is_const;      /* 1: value is c_*; 0: value is table[w] */
+    int32_t is_const;      /* 1: value is c_*; 0: value is table[w - lo] */
     int32_t _pad;
     int64_t c_i64;
     double  c_f64;
     const void *table;     /* int64_t[len] or double[len] according to the model dtype */
     int64_t len;
+    int64_t lo;            /* width of table[0] (0 for plain tables) */
 } cp_component_t;
 
 typedef struct cp_model {

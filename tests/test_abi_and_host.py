@@ -67,12 +67,31 @@ def test_equi_closed_forms_match_library_and_oracle(orc):
             assert Ka.value == Kb and a[:Kb + 1].tolist() == b[:Kb + 1].tolist()
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors vs the C header itself: sizes and field offsets printed by a program compiled from
+    include/chainpart_types.h."""
+    import subprocess
     from chainpartitioners_jl_amd import models as M
-    # sizes implied by include/chainpart_types.h on LP64
-    assert C.sizeof(M.cp_component_t) == 40
-    assert C.sizeof(M.cp_model_t) == 8 + 40 + 40 + 16 + 8 + 40 * (2 + 2 * M.CP_MAX_R)
-    assert C.sizeof(M.cp_rowpart_t) == 24
+    src = tmp_path / "layout.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "chainpart_types.h"
+int main(void) {
+    printf("%zu %zu %zu ", sizeof(cp_component_t), sizeof(cp_model_t), sizeof(cp_rowpart_t));
+    printf("%zu %zu %zu ", offsetof(cp_component_t, table), offsetof(cp_component_t, len), offsetof(cp_component_t, lo));
+    printf("%zu %zu %zu %zu %zu\\n", offsetof(cp_model_t, p_f64), offsetof(cp_model_t, alpha_k), offsetof(cp_model_t, R),
+           offsetof(cp_model_t, alpha_row), offsetof(cp_model_t, beta_col));
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(M.cp_component_t), C.sizeof(M.cp_model_t), C.sizeof(M.cp_rowpart_t),
+            M.cp_component_t.table.offset, M.cp_component_t.len.offset, M.cp_component_t.lo.offset,
+            M.cp_model_t.p_f64.offset, M.cp_model_t.alpha_k.offset, M.cp_model_t.R.offset,
+            M.cp_model_t.alpha_row.offset, M.cp_model_t.beta_col.offset]
+    assert got == want
 
 
 def test_model_promotion_rules():

@@ -108,3 +108,18 @@ def test_pack_dynamic_scan_path(hip, orc):
                     hip.set_option("force_brute", 0)
                 assert got == lit, (n, w, fs.index(f), "scan vs literal kernel")
                 assert np.all(np.diff(got.spl) <= w)
+
+
+def test_convex_chunker_on_a_non_convex_cost_at_scale(hip, orc):
+    """Config-4 shape: ConvexTotalChunker(ConstrainedCost(col_block_model, VertexCount(), 8)) on a banded matrix.  The cost is
+    not convex, the candidate stack goes stale from n ~ 1e5 on and the reference evaluates the closure at NEGATIVE widths
+    (ConvexTotalChunker.jl:76,99): the tables cover them (cp_component_t.lo) and the device must follow the oracle exactly."""
+    A = banded(120000, 16, 0.5, 4)
+    f = cp.ConstrainedCost(cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w), cp.VertexCount(), 8)
+    got = cp.pack_stripe(A, cp.ConvexTotalChunker(f), backend=hip)
+    want = cp.pack_stripe(A, cp.ConvexTotalChunker(f), backend=orc)
+    assert got == want
+    assert np.all(np.diff(got.spl) <= 8)
+    got = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=hip)
+    want = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=orc)
+    assert got == want
