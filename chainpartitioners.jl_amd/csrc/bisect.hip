@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, doubl
     spl[0] = 1;
     spl[K] = n + 1;
     int64_t probes = 0;
+    bool stuck = false;
     while (c_lo * (1 + eps) < c_hi) {                     // :41
         double c = (c_lo + c_hi) / 2;
         probes++;
@@ -120,6 +121,9 @@ __global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, doubl
         }
         bool feas = false;
         if (chk) feas = le_f64(oracle_eval_dev(O, spl[K - 1], spl[K], K), c);
+        // no bound moved (or far too many probes): the reference's loop would repeat this probe forever -- it does for
+        // non-positive bounds, where c_lo * (1 + eps) < c_hi can never become false.  A kernel must not.
+        if ((feas ? c_hi : c_lo) == c || probes > 4096) { stuck = true; break; }
         if (feas) {
             c_hi = c;
             int64_t *dst = flip ? spl_lo : spl_hi;
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, doubl
     }
     const int64_t *src = flip ? spl_lo : spl_hi;
     for (int64_t k = lane; k <= K; k += 64) out[k] = src[k];
-    if (lane == 0) *nprobes = probes;
+    if (lane == 0) *nprobes = stuck ? -1 : probes;
 }
 
 // ------------------------------------------------------------------ BisectIndexBottleneckSplitter.jl:5-83, flip :85-166
@@ -237,9 +241,12 @@ int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, d
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect<TC>), dim3(1), dim3(64), 0, s, O, K, c_lo, c_hi, eps, flip, d_lo, d_hi, d_spl, d_out, d_np);
     }
     CP_HIP(hipGetLastError());
+    int64_t np_host = 0;
     CP_HIP(hipMemcpyAsync(spl_out, d_out, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(&np_host, d_np, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     prof_collect();
+    CP_REQUIRE(np_host >= 0, CP_EINVAL, "cost bisection cannot terminate on these bounds (the reference loops forever: non-positive costs)");
     return CP_OK;
 }
 

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(LZ_T) k_lazy_bisect(DevModel<TC> M, int64_t n,
         c_lo = c_lo < v ? v : c_lo;
     }
     int64_t probes = 0;
-    bool first = true;
+    bool first = true, stuck = false;
     while (c_lo * (1 + eps) < c_hi) {                                  // :237-247, :249-257
         double c = (c_lo + c_hi) / 2;
         probes++;
@@ -161,6 +161,8 @@ __global__ void __launch_bounds__(LZ_T) k_lazy_bisect(DevModel<TC> M, int64_t n,
             if (tid == 0) for (int64_t t = k; t <= K; t++) spl[t] = n + 1;    // :181-184 / :221-224
         }
         __syncthreads();
+        // no bound moved: the reference would repeat this probe forever (non-positive bounds); block-uniform exit
+        if ((res ? c_hi : c_lo) == c || probes > 4096) { stuck = true; break; }
         if (res) {
             c_hi = c;
             for (int64_t t = tid; t <= K; t += LZ_T) spl_hi[t] = spl[t];
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(LZ_T) k_lazy_bisect(DevModel<TC> M, int64_t n,
         first = false;
         __syncthreads();
     }
-    if (tid == 0) *nprobes = probes;
+    if (tid == 0) *nprobes = stuck ? -1 : probes;
 }
 
 template <typename TC>
@@ -188,9 +190,12 @@ int32_t run_lazy(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, dou
                            c_lo, c_hi, eps, d_spl, d_hi, d_np);
     }
     CP_HIP(hipGetLastError());
+    int64_t np_host = 0;
     CP_HIP(hipMemcpyAsync(spl_out, d_hi, sizeof(int64_t) * (size_t)(K + 1), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(&np_host, d_np, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     prof_collect();
+    CP_REQUIRE(np_host >= 0, CP_EINVAL, "cost bisection cannot terminate on these bounds (the reference loops forever: non-positive costs)");
     return CP_OK;
 }
 

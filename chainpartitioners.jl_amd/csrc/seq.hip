@@ -646,10 +646,11 @@ static void seq_oracle(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *P
 
 // pairs inside a VertexCount window come from a table built in one parallel pass over the link arrays
 template <typename TC>
-static void seq_window_table(cp_csr_s *A, const cp_model_t *mdl, const cp_model_t *w, int64_t wmax, SeqCtx<TC> &C)
+static void seq_window_table(cp_csr_s *A, const cp_model_t *mdl, const cp_model_t *w, int64_t wmax, SeqCtx<TC> &C, int64_t span = 1)
 {
     if (!w || w->kind != CP_MODEL_VERTEX_COUNT || mdl->kind == CP_MODEL_BLOCK || mdl->alpha_k || wmax < 1) return;
-    int64_t n = A->n, Wc = wmax;
+    // span 2: the convex chunker's staircase sub-problems pair columns up to two windows apart (ConvexTotalChunker.jl:246)
+    int64_t n = A->n, Wc = span * wmax + (span > 1 ? 2 : 0);
     if ((double)(n + 2) * (double)(Wc + 1) > 6e8) return;
     hipStream_t s = A->stream;
     ensure_links(A);
@@ -733,7 +734,7 @@ int32_t run_pack_convex(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *
     int64_t n = A->n, cap = 2 * n + 4;
     std::unique_ptr<SeqCtx<TC>> C(new SeqCtx<TC>());
     seq_oracle<TC>(A, mdl, Pi, *C);
-    seq_window_table<TC>(A, mdl, w, wi, *C);
+    seq_window_table<TC>(A, mdl, w, wi, *C, 2);
     SeqWeight W = make_weight(A, w, wi, wf);
     int constrained = W.kind != CP_MODEL_FEASIBLE;
     DBuf<Ext<TC>> cst((size_t)n + 2), sig_cst((size_t)cap);

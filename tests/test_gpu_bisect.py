@@ -38,3 +38,16 @@ def test_bisect_within_eps_of_optimum(hip):
             for eps in (0.1, 0.01):
                 got = cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(f, eps), backend=hip)
                 assert cp.bottleneck_value(A, got, f, backend=hip) <= c * (1 + eps)
+
+
+def test_cost_bisection_that_cannot_terminate_is_reported(hip, orc):
+    """Non-positive cost bounds: `while c_lo * (1 + eps) < c_hi` never becomes false and the reference spins forever
+    (BisectCostBottleneckSplitter.jl:41, LazyBisectCostBottleneckSplitter.jl:249).  A kernel must not: both the device
+    and the oracle report a violated precondition once a probe moves no bound."""
+    A = suitesparse_shaped(300, 4, 1)
+    for b in (hip, orc):
+        for meth in (cp.BisectCostBottleneckSplitter(cp.AffineWorkModel(-3, 0, 0), 0.01),
+                     cp.BisectCostBottleneckSplitter(cp.AffineConnectivityModel(-50, 0, 0, 0), 0.01),
+                     cp.LazyBisectCostBottleneckSplitter(cp.AffineConnectivityModel(-50, 0, 0, 0), 0.01)):
+            with pytest.raises(AssertionError):
+                cp.partition_stripe(A, 4, meth, backend=b)

@@ -36,7 +36,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n2", type=int, default=1_000_000)
     ap.add_argument("--n4", type=int, default=5_000_000)
-    ap.add_argument("--skip-convex", action="store_true", help="the one-wave ConvexTotalChunker kernel takes ~6 us per column")
+    ap.add_argument("--skip-convex", action="store_true", help="the one-wave ConvexTotalChunker kernel takes microseconds per column")
+    ap.add_argument("--n4-convex", type=int, default=0, help="size for the ConvexTotalChunker line (default: --n4)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     from chainpartitioners_jl_amd import _lib
@@ -80,23 +81,29 @@ def main():
         print(json.dumps(out))
         return
     # ---- config 4
-    n = args.n4
-    colptr, rowval = banded_dev(n, 16, 0.5, 0xDEADBEEF + 4, dev)
-    h = hip.csr_from_device(n, n, rowval.numel(), colptr.data_ptr(), rowval.data_ptr())
-    f = cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w, w_table=9)
-    mm = f.marshal(); wm = cp.VertexCount().marshal()
-    splc = np.zeros(n + 1, dtype=np.int64); Kout = np.zeros(1, dtype=np.int64)
-    for name, fn in (("convex", hip.pack_convex), ("dynamic", hip.pack_dynamic)):
+    from chainpartitioners_jl_amd import api
+    fc = cp.ConstrainedCost(cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w), cp.VertexCount(), 8)
+    for name, fname, n in (("convex", "pack_convex", args.n4_convex or args.n4), ("dynamic", "pack_dynamic", args.n4)):
         if name == "convex" and args.skip_convex:
             continue
+        colptr, rowval = banded_dev(n, 16, 0.5, 0xDEADBEEF + 4, dev)
+        h = hip.csr_from_device(n, n, rowval.numel(), colptr.data_ptr(), rowval.data_ptr())
+        class _Shape:            # the host mirror sizes closure tables from the matrix shape only
+            pass
+        sh = _Shape(); sh.n = n; sh.m = n
+        _, mm, wm, wi, wf, _, keep = api._marshal(sh, fc, None, stack_method=(name == "convex"))
+        fn = getattr(hip, fname)
+        splc = np.zeros(n + 1, dtype=np.int64); Kout = np.zeros(1, dtype=np.int64)
         def run():
             hip.reset_cache(h)
-            rc = fn(h, mm, None, wm, 8, 8.0, splc, Kout)
+            rc = fn(h, mm, None, wm, wi, wf, splc, Kout)
             assert rc == 0, hip.last_error()
         t = timeit(run, reps=1)
         Kc = int(Kout[0])
-        out["cfg4_pack_" + name] = {"n": n, "nnz": int(rowval.numel()), "w_max": 8, "seconds": t, "chunks": Kc,
+        out["cfg4_pack_" + name] = {"n": n, "nnz": int(rowval.numel()), "w_max": 8, "seconds": t, "us_per_column": t / n * 1e6, "chunks": Kc,
                                     "width_ok": bool(np.all(np.diff(splc[:Kc + 1]) <= 8) and splc[Kc] == n + 1)}
+        hip.csr_destroy(h)
+        del colptr, rowval
     print(json.dumps(out))
 
 
