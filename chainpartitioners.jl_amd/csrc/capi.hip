@@ -353,7 +353,7 @@ static int32_t csr_create_impl(int64_t m, int64_t n, int64_t N, const int64_t *c
     return guarded([&]() -> int32_t {
         CP_REQUIRE(out && colptr && (rowval || N == 0), CP_EINVAL, "null argument");
         CP_REQUIRE(m >= 0 && n >= 0 && N >= 0, CP_EINVAL, "negative dimension");
-        CP_REQUIRE(n < (int64_t)1 << 30 && m < (int64_t)1 << 30 && N < ((int64_t)1 << 31) - 2, CP_EINVAL,
+        CP_REQUIRE(n < (int64_t)1 << 30 && m < (int64_t)1 << 30 && N < ((int64_t)1 << 31) - 65536, CP_EINVAL,     // 32-bit entry positions; kernels look ahead by up to 16 Ki entries
                    "dimensions exceed the 32-bit link-array layout");
         CP_REQUIRE(cp_device_count() > 0, CP_EHIP, "no HIP device visible: libchainpart has no CPU fallback");
         CP_HIP(hipSetDevice(device));

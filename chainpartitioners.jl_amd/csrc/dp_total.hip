@@ -18,10 +18,15 @@
 //        needed, and the same columns serve every set bit b of r (different thresholds B_b): one row-major
 //        reduction pass per round (k_rpass_*), N/2 link entries per round.
 //      left part: columns p = B-1 .. a join a part ending before r: + #{q in p : next[q] >= r}, one
-//        candidate per column.  All left steps of a round are flattened (1 + B - a elements per row-task),
-//        streamed wave-cooperatively (coalesced 64-entry chunks, ballot/popcount per column), segment-scanned
-//        with wave shuffles, evaluated and arg-min reduced in the same kernel (k_lpass).  Tasks that span
-//        several 256-step tiles finish in k_open / k_fix.
+//        candidate per column.  Per round (k_setup_short -> scan -> k_tile_t0 -> k_lpass -> k_span_short / k_open / k_fix):
+//          - tasks with a handful of candidates are finished by one lane in k_setup_short;
+//          - the left steps of the other tasks are flattened (1 + B - a elements per task) and cut into 256-step tiles;
+//          - a tile that lies inside ONE task (4 of 5 tiles) is one contiguous run of the link array: k_lpass streams
+//            it with suffix counts and evaluates it with tile-local counts (the costs are affine in the counts);
+//          - the other tiles are counted cooperatively (ballot/popcount per column), segment-scanned with wave
+//            shuffles, evaluated and arg-min reduced per task;
+//          - tasks spanning tiles are merged by k_span_short (one lane), or k_open + k_fix (work lists).
+//  * plane arrays are stored level-major (prow): the rows of one round are contiguous in every plane.
 #include "csr.hpp"
 #include "model.hpp"
 #include "dp.hpp"
