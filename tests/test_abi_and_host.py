@@ -99,3 +99,10 @@ def test_model_promotion_rules():
     assert cp.AffineConnectivityModel(0.0, 0, 0, 1).dtype == 1           # promote -> Float64
     assert cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[1, 2]).dtype == 0
     assert cp.AffineWorkModel(0, 10, 1)(3, 7) == 37
+
+
+def test_plain_c_client_builds_against_the_header():
+    """examples/c_abi_demo.c uses nothing but include/chainpart.h and the shared library (no Python, no torch types)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "clean", "c_abi_demo"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "examples", "c_abi_demo"))

@@ -130,3 +130,12 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
                 finally:
                     hip.set_option("short_t", 4); hip.set_option("short_e", 64)
                 assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, M_)
+
+
+def test_plain_c_client_runs(hip):
+    """The C ABI driven from a C program (examples/c_abi_demo.c) in a child process: no Python between caller and library."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "c_abi_demo"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "examples", "c_abi_demo")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
