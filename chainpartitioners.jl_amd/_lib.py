@@ -24,6 +24,7 @@ SYMBOLS = [
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
+    "cp_adjoint", "cp_csr_download",
 ]
 
 _lib = None
@@ -95,6 +96,31 @@ class HipBackend:
 
     def csr_destroy(self, h):
         self.lib.cp_csr_destroy(h)
+
+    def adjoint(self, A):
+        """adjointpattern(A) on the device; the result's device handle stays registered, so a following
+        partition_stripe(adj_A, ...) needs no upload."""
+        from .types import SparseMatrixCSC
+        t = C.c_void_p()
+        rc = self.lib.cp_adjoint(self._h(A), C.byref(t))
+        if rc != 0:
+            raise RuntimeError(f"cp_adjoint failed ({rc}): {self.last_error()}")
+        dims = np.zeros(3, dtype=np.int64)
+        self.lib.cp_csr_download(t, _p(dims), None, None)
+        m, n, N = (int(x) for x in dims)
+        colptr = np.zeros(n + 1, dtype=np.int64); rowval = np.zeros(max(N, 1), dtype=np.int64)
+        rc = self.lib.cp_csr_download(t, _p(dims), _p(colptr), _p(rowval))
+        if rc != 0:
+            self.lib.cp_csr_destroy(t)
+            raise RuntimeError(f"cp_csr_download failed ({rc}): {self.last_error()}")
+        T = SparseMatrixCSC(m, n, colptr, rowval[:N])
+        lib, handles, key = self.lib, self._handles, id(T)
+
+        def _drop(_ref, key=key, t=t):
+            handles.pop(key, None)
+            lib.cp_csr_destroy(t)
+        self._handles[key] = (weakref.ref(T, _drop), t)
+        return T
 
     def reset_cache(self, A_or_handle):
         h = A_or_handle if isinstance(A_or_handle, C.c_void_p) else self.csr(A_or_handle)

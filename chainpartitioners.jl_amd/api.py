@@ -252,6 +252,12 @@ def bottleneck_value(A, Phi, mdl, Pi=None, *, backend=None):
     return _objective(M.CP_COMBINE_MAX, A, Phi, M.split_constraint(mdl)[0], Pi, backend)
 
 
+def adjointpattern(A: SparseMatrixCSC, *, backend=None) -> SparseMatrixCSC:
+    """adjointpattern(A) (util.jl:67-95): transposed pattern, computed on the device (cp_adjoint); the returned matrix
+    keeps its device handle, so partitioning it needs no upload."""
+    return get_backend(backend).adjoint(A)
+
+
 # ---------------------------------------------------------------- counting structures
 class CountMatrix:
     """netcount / selfnetcount / dominancecount object: obj[j, j'] (or obj(i, j)), vectorised."""

@@ -389,6 +389,34 @@ int32_t cp_csr_destroy(cp_csr_t A)
     return CP_OK;
 }
 
+int32_t cp_adjoint(cp_csr_t A, cp_csr_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && out, CP_EINVAL, "null argument");
+        CP_HIP(hipSetDevice(A->device));
+        std::unique_ptr<cp_csr_s> T(new cp_csr_s());
+        T->device = A->device;
+        CP_HIP(hipStreamCreate(&T->stream));
+        T->own_stream = true;
+        csr_adjoint(A, T.get());
+        *out = T.release();
+        return CP_OK;
+    });
+}
+
+int32_t cp_csr_download(cp_csr_t A, int64_t *dims_out, int64_t *colptr_out, int64_t *rowval_out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A, CP_EINVAL, "null argument");
+        if (dims_out) { dims_out[0] = A->m; dims_out[1] = A->n; dims_out[2] = A->N; }
+        if (!colptr_out) return CP_OK;
+        CP_REQUIRE(rowval_out || A->N == 0, CP_EINVAL, "rowval_out is null");
+        CP_HIP(hipSetDevice(A->device));
+        csr_download(A, colptr_out, rowval_out);
+        return CP_OK;
+    });
+}
+
 int32_t cp_csr_reset_cache(cp_csr_t A)
 {
     if (!A) return CP_EINVAL;

@@ -156,6 +156,46 @@ void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool 
     CP_HIP(hipStreamSynchronize(s));
 }
 
+// ------------------------------------------------------------------ adjointpattern / download
+__global__ void k_adj_rows(const int32_t *__restrict__ tq, const int32_t *__restrict__ col, int32_t *__restrict__ row_t, int64_t N)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) row_t[q] = col[tq[q]];             // row-major order of A = column-major order of its adjoint
+}
+__global__ void k_to_julia(const int64_t *__restrict__ pos, const int32_t *__restrict__ row, int64_t *__restrict__ colptr,
+                           int64_t *__restrict__ rowval, int64_t n1, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) colptr[i] = pos[i] + 1;
+    if (i < N) rowval[i] = (int64_t)row[i] + 1;
+}
+
+void csr_adjoint(cp_csr_s *A, cp_csr_s *T)
+{
+    ensure_links(A);                               // tpos (row pointer) and tq (nonzeros by (row, column)) come from here
+    hipStream_t s = A->stream;
+    T->m = A->n; T->n = A->m; T->N = A->N;
+    T->pos.alloc((size_t)T->n + 1);
+    T->row.alloc((size_t)(T->N > 0 ? T->N : 1));
+    CP_HIP(hipMemcpyAsync(T->pos.p, A->tpos.p, sizeof(int64_t) * (size_t)(T->n + 1), hipMemcpyDeviceToDevice, s));
+    if (T->N > 0)
+        hipLaunchKernelGGL(k_adj_rows, dim3((unsigned)cdiv(T->N, 256)), dim3(256), 0, s, A->tq.p, A->col.p, T->row.p, T->N);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipStreamSynchronize(s));
+}
+
+void csr_download(cp_csr_s *A, int64_t *colptr, int64_t *rowval)
+{
+    hipStream_t s = A->stream;
+    int64_t n1 = A->n + 1, N = A->N, mx = n1 > N ? n1 : N;
+    DBuf<int64_t> dc((size_t)n1), dr((size_t)(N > 0 ? N : 1));
+    hipLaunchKernelGGL(k_to_julia, dim3((unsigned)cdiv(mx, 256)), dim3(256), 0, s, A->pos.p, A->row.p, dc.p, dr.p, n1, N);
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipMemcpyAsync(colptr, dc.p, sizeof(int64_t) * (size_t)n1, hipMemcpyDeviceToHost, s));
+    if (N > 0) CP_HIP(hipMemcpyAsync(rowval, dr.p, sizeof(int64_t) * (size_t)N, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+}
+
 // ------------------------------------------------------------------ link arrays
 // col[q]: one wave per 64 columns would idle on skew; a flat binary search per nonzero is regular.
 __global__ void k_fill_col(const int64_t *__restrict__ pos, int32_t *__restrict__ col, int64_t n, int64_t N)

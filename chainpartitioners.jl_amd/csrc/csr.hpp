@@ -34,4 +34,6 @@ void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool 
 void ensure_links(cp_csr_s *A);
 void ensure_self(cp_csr_s *A);
 void drop_cache(cp_csr_s *A);
+void csr_adjoint(cp_csr_s *A, cp_csr_s *T);                                 // T: fresh handle (device / stream set by the caller)
+void csr_download(cp_csr_s *A, int64_t *colptr, int64_t *rowval);
 }  // namespace cpk

@@ -13,7 +13,7 @@ import numpy as np
 
 __all__ = [
     "SparseMatrixCSC", "SplitPartition", "DomainPartition", "MapPartition",
-    "NoHint", "RandomHint", "SparseHint", "StepHint", "adjointpattern",
+    "NoHint", "RandomHint", "SparseHint", "StepHint",
 ]
 
 
@@ -80,16 +80,6 @@ class SparseMatrixCSC:
 
     def __repr__(self):
         return f"SparseMatrixCSC({self.m}x{self.n}, nnz={self.nnz})"
-
-
-def adjointpattern(A: SparseMatrixCSC) -> SparseMatrixCSC:
-    """CSC transpose of the pattern by counting sort (reference: util.jl:67-95)."""
-    m, n = A.shape
-    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), np.diff(A.colptr))
-    order = np.argsort(A.rowval, kind="stable")
-    cnt = np.bincount(A.rowval - 1, minlength=m)
-    pos = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int64)
-    return SparseMatrixCSC(n, m, pos, cols[order])
 
 
 class SplitPartition:

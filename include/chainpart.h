@@ -39,6 +39,13 @@ int32_t cp_csr_create(int64_t m, int64_t n, int64_t N, const int64_t *colptr, co
 int32_t cp_csr_create_device(int64_t m, int64_t n, int64_t N, const int64_t *colptr_device,
                              const int64_t *rowval_device, int32_t device, cp_csr_t *out);
 int32_t cp_csr_destroy(cp_csr_t csr);
+/* adjointpattern(A) (util.jl:67-95): the transposed pattern (n x m, rows of every column ascending) as a NEW
+ * device-resident handle -- the counting sort the reference runs is the (row, column) order the link-array build
+ * already produces.  First block of SURVEY 8(f)-4 (the 2-D callers partition A and its adjoint alternately). */
+int32_t cp_adjoint(cp_csr_t csr, cp_csr_t *out);
+/* copy a handle's pattern back to the host in Julia's layout: colptr int64[n+1], rowval int64[nnz], 1-based;
+ * dims_out = {m, n, nnz} (call with NULL arrays to query the sizes first) */
+int32_t cp_csr_download(cp_csr_t csr, int64_t *dims_out, int64_t *colptr_out, int64_t *rowval_out);
 /* drop cached derived structures (link arrays, counters) so the next call rebuilds them:
  * lets a benchmark time "one partition_stripe call including oracle construction" */
 int32_t cp_csr_reset_cache(cp_csr_t csr);

@@ -62,6 +62,15 @@ class OracleBackend:
         return lib().orc_pack_dynamic(*self._A(A), mm.ptr, C.byref(rp) if rp is not None else None,
                                       wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
 
+    def adjoint(self, A):
+        """adjointpattern(A): CSC transpose of the pattern by a stable counting sort (util.jl:67-95)."""
+        m, n = A.shape
+        cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), np.diff(A.colptr))
+        order = np.argsort(A.rowval, kind="stable")
+        cnt = np.bincount(A.rowval - 1, minlength=m)
+        pos = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int64)
+        return type(A)(n, m, pos, cols[order])
+
     def partition_bisect_index(self, A, K, mm, flip, spl):
         pr = np.zeros(1, dtype=np.int64)
         rc = lib().orc_partition_bisect_index(*self._A(A), _i64(K), mm.ptr, C.c_int32(flip), _p(spl), _p(pr))

@@ -113,3 +113,18 @@ def test_power_work_model_on_device(hip, orc):
         ref = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=orc)
         va, vb = cp.total_value(A, got, f, backend=orc), cp.total_value(A, ref, f, backend=orc)
         assert abs(va - vb) <= 1e-9 * max(1.0, abs(vb))
+
+
+def test_adjointpattern_on_device(hip, orc):
+    """cp_adjoint / cp_csr_download: same arrays as the reference's counting sort; the adjoint keeps its device handle and can
+    be partitioned right away (the alternating 2-D callers do exactly that)."""
+    rng = np.random.default_rng(61)
+    for A in _mats(34) + [suitesparse_shaped(20000, 8, 6), sprand(300, 5000, 0.01, rng), sprand(5000, 300, 0.01, rng)]:
+        T = cp.adjointpattern(A, backend=hip)
+        W = cp.adjointpattern(A, backend=orc)
+        assert T.shape == W.shape and np.array_equal(T.colptr, W.colptr) and np.array_equal(T.rowval, W.rowval)
+        f = cp.AffineConnectivityModel(0, 3, 1, 3)
+        K = 3
+        got = cp.partition_stripe(T, K, cp.DynamicTotalSplitter(f), backend=hip)
+        want = cp.partition_stripe(W, K, cp.DynamicTotalSplitter(f), backend=orc)
+        assert got == want

@@ -235,7 +235,7 @@ def test_block_costs(orc):
                     assert got == block_total_direct(A, Pi, Phi, mdl)
     # chunkers with a block model: DP optimum respected, width limit honoured (test_Partitioners.jl:225-248)
     A = sprand(20, 24, 0.2, rng)
-    Pi = cp.pack_stripe(cp.adjointpattern(A), cp.EquiChunker(2))
+    Pi = cp.pack_stripe(cp.adjointpattern(A, backend=orc), cp.EquiChunker(2))
     mdl = cp.BlockComponentCostModel(0, 0, (10, lambda x: x), (2, lambda x: 2 * x))
     f = cp.ConstrainedCost(mdl, cp.VertexCount(), 4)
     Phi = cp.pack_stripe(A, cp.DynamicTotalChunker(f), Pi, backend=orc)

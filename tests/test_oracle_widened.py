@@ -302,3 +302,18 @@ def test_concave_total_chunker_is_optimal(orc):
             if isinstance(f, cp.ConstrainedCost):
                 assert _widths_ok(A, got, w, f.w_max) and _widths_ok(A, ref, w, f.w_max)
             assert _approx(cp.total_value(A, got, f, backend=orc), cp.total_value(A, ref, f, backend=orc)), (A, f)
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) row 4, first block: adjointpattern
+def test_adjointpattern_oracle(orc):
+    """util.jl:67-95: the transposed pattern with rows ascending in every column; pinned against scipy's transpose."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(60)
+    for A in small_matrices(60, trials=1) + [golden_matrices()["LPnetlib/lp_blend"]]:
+        T = cp.adjointpattern(A, backend=orc)
+        assert T.shape == (A.n, A.m) and T.nnz == A.nnz
+        S = sp.csc_matrix((np.ones(A.nnz), A.rowval - 1, A.colptr - 1), shape=(A.m, A.n)).T.tocsc()
+        S.sort_indices()
+        assert np.array_equal(T.colptr, S.indptr + 1) and np.array_equal(T.rowval, S.indices + 1)
+        TT = cp.adjointpattern(T, backend=orc)
+        assert np.array_equal(TT.colptr, A.colptr) and np.array_equal(TT.rowval, A.rowval)
