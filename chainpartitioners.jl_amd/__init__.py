@@ -7,7 +7,7 @@ hand-written HIP kernels behind the C ABI of include/chainpart.h (csrc/).
 from .types import *          # noqa: F401,F403
 from .types import to_map, to_domain   # noqa: F401
 from .models import (PowerWorkModel, ConvexWorkModel, ConcaveWorkModel,   # noqa: F401
-                     AffineWorkModel, AffineConnectivityModel, AffineHyperedgeCutModel,      # noqa: F401
+                     AffineWorkModel, AffinePrimaryConnectivityModel, AffineSecondaryConnectivityModel, AffineConnectivityModel, AffineHyperedgeCutModel,      # noqa: F401
                      ColumnBlockComponentCostModel, BlockComponentCostModel, VertexCount, FeasibleCost,
                      ConstrainedCost, EquiSplitter, EquiChunker, DynamicTotalSplitter,
                      DynamicBottleneckSplitter, DynamicTotalChunker, DynamicBottleneckChunker,

@@ -224,10 +224,15 @@ def oracle_stripe(hint, mdl, A, Pi=None, *, backend=None) -> Oracle:
     return Oracle(hint, mdl, A, Pi, get_backend(backend))
 
 
-def bound_stripe(A, K, mdl, *, backend=None):
+def bound_stripe(A, K, mdl, Pi=None, *, backend=None):
+    """bound_stripe(A, K, [Pi], mdl): Pi only matters to the secondary connectivity model (Costs.jl:17-19)."""
     b = get_backend(backend)
     mm = mdl.marshal(w_table=A.n + 1)
-    rc, lo, hi = b.bound_stripe(A, int(K), mm)
+    if Pi is not None and isinstance(mdl, M.AffineSecondaryConnectivityModel):
+        rp, keep = _rowpart(Pi)
+        rc, lo, hi = b.bound_stripe_pi(A, int(K), rp, mm)
+    else:
+        rc, lo, hi = b.bound_stripe(A, int(K), mm)
     _check(rc, "bound_stripe", b)
     return lo, hi
 

@@ -26,7 +26,8 @@ import numpy as np
 
 CP_I64, CP_F64 = 0, 1
 (CP_MODEL_FEASIBLE, CP_MODEL_WORK, CP_MODEL_CONNECTIVITY, CP_MODEL_HYPEREDGE_CUT,
- CP_MODEL_COLBLOCK, CP_MODEL_BLOCK, CP_MODEL_VERTEX_COUNT, CP_MODEL_POWER_WORK) = range(8)
+ CP_MODEL_COLBLOCK, CP_MODEL_BLOCK, CP_MODEL_VERTEX_COUNT, CP_MODEL_POWER_WORK, CP_MODEL_PRIMARY,
+ CP_MODEL_SECONDARY) = range(10)
 CP_COMBINE_SUM, CP_COMBINE_MAX = 0, 1
 CP_ORDER_SPLITTER, CP_ORDER_CHUNKER = 0, 1
 CP_MAX_R = 4
@@ -203,6 +204,35 @@ class AffineHyperedgeCutModel(_Model):
         a = self.alpha if self.alpha_k is None or k is None else self.alpha_k[k - 1]
         return (a + n_vertices * self.beta_vertex + n_pins * self.beta_pin
                 + n_self * self.beta_self_net + n_cut * self.beta_cut_net)
+
+
+class AffinePrimaryConnectivityModel(_Model):
+    """PrimaryConnectivityCosts.jl:5-20: nets of a column part split by the row partition Pi into local (owned by the same
+    part number) and remote ones.  Needs Pi (any partition of the rows)."""
+    kind = CP_MODEL_PRIMARY
+    needs_rowpart = True
+
+    def __init__(self, alpha=0, beta_vertex=0, beta_pin=0, beta_local_net=0, beta_remote_net=0, *, alpha_k=None):
+        self.alpha, self.beta_vertex, self.beta_pin = alpha, beta_vertex, beta_pin
+        self.beta_local_net, self.beta_remote_net = beta_local_net, beta_remote_net
+        self.alpha_k = alpha_k
+        self.dtype = _promote(alpha, beta_vertex, beta_pin, beta_local_net, beta_remote_net, *([alpha_k] if alpha_k is not None else []))
+
+    def _params(self):
+        return [self.alpha, self.beta_vertex, self.beta_pin, self.beta_local_net, self.beta_remote_net]
+
+    def _alpha_k(self):
+        return self.alpha_k
+
+    def __call__(self, n_vertices, n_pins, n_local, n_remote, k=None):
+        a = self.alpha if self.alpha_k is None or k is None else self.alpha_k[k - 1]
+        return a + n_vertices * self.beta_vertex + n_pins * self.beta_pin + n_local * self.beta_local_net + n_remote * self.beta_remote_net
+
+
+class AffineSecondaryConnectivityModel(AffinePrimaryConnectivityModel):
+    """SecondaryConnectivityCosts.jl:5-20: the cost of giving a range of columns to part k of the SplitPartition Pi of the
+    rows -- the alternating partitioners call it on the adjoint, with Pi the column split found in the previous sweep."""
+    kind = CP_MODEL_SECONDARY
 
 
 def _tabulate(f, lo, hi, npdt):

@@ -44,6 +44,11 @@ extern "C" {
 #define CP_MODEL_COLBLOCK       4  /* alpha_col(w) + nets*beta_col(w) */
 #define CP_MODEL_BLOCK          5  /* rank-R separable 2-D VBR cost, needs a row partition */
 #define CP_MODEL_VERTEX_COUNT   6  /* VertexCount(): j' - j, always Int */
+#define CP_MODEL_PRIMARY        8  /* AffinePrimaryConnectivityModel: alpha + nv*b_vertex + np*b_pin + local*b_local_net +
+                                      remote*b_remote_net; nets of the part split by the row partition Pi into those owned by
+                                      the same part number (local) and the others (PrimaryConnectivityCosts.jl:5-20, :53-78) */
+#define CP_MODEL_SECONDARY      9  /* AffineSecondaryConnectivityModel (SecondaryConnectivityCosts.jl:5-20, :63-86): cost of
+                                      giving the column range [j, j') to part k of the SplitPartition Pi of the ROWS */
 #define CP_MODEL_POWER_WORK     7  /* alpha + (nv*b_vertex + np*b_pin)^gamma, Float64 only, gamma in p_f64[3]: the
                                       ConvexWorkModel (gamma = 0.8) / ConcaveWorkModel (gamma = 2) the reference's
                                       tests define (test/test_Partitioners.jl:54-74); gamma == 2 is evaluated as x*x
@@ -57,6 +62,8 @@ extern "C" {
 #define CP_P_SELF_NET   3
 #define CP_P_CUT_NET    4
 #define CP_P_GAMMA      3   /* power work model: the exponent */
+#define CP_P_LOCAL_NET  3   /* primary / secondary connectivity */
+#define CP_P_REMOTE_NET 4
 
 #define CP_MAX_R 4
 

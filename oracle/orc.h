@@ -74,6 +74,11 @@ int32_t orc_bound_stripe(int64_t m, int64_t n, int64_t N, const int64_t *pos, co
                          int64_t K, const cp_model_t *mdl,
                          int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);
 
+/* bound_stripe(A, K, Pi, mdl) Costs.jl:17-19, SecondaryConnectivityCosts.jl:21-31 */
+int32_t orc_bound_stripe_pi(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                            int64_t K, const cp_rowpart_t *Pi, const cp_model_t *mdl,
+                            int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);
+
 /* total_value / bottleneck_value (Costs.jl:26-66) */
 int32_t orc_objective(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
                       int64_t K, const int64_t *spl, const cp_model_t *mdl, const cp_rowpart_t *Pi,

@@ -12,6 +12,8 @@
                                    const int64_t *, const int64_t *, const int64_t *, T *);                \
     int32_t orc_api_bound_stripe##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t,  \
                                     const cp_model_t *, T *, T *);                                         \
+    int32_t orc_api_bound_stripe_pi##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t,   \
+                                       const cp_rowpart_t *, const cp_model_t *, T *, T *);                    \
     int32_t orc_api_objective##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t,     \
                                  const int64_t *, const cp_model_t *, const cp_rowpart_t *, int32_t, T *); \
     int32_t orc_api_partition_dynamic##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,      \
@@ -68,6 +70,18 @@ int32_t orc_bound_stripe(int64_t m, int64_t n, int64_t N, const int64_t *pos, co
         return rc;
     }
     return orc_api_bound_stripe_f64(m, n, N, pos, idx, K, mdl, lo_f64, hi_f64);
+}
+
+int32_t orc_bound_stripe_pi(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                            int64_t K, const cp_rowpart_t *Pi, const cp_model_t *mdl,
+                            int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64)
+{
+    if (IS_I(mdl)) {
+        int32_t rc = orc_api_bound_stripe_pi_i64(m, n, N, pos, idx, K, Pi, mdl, lo_i64, hi_i64);
+        if (rc == CP_OK) { *lo_f64 = (double)*lo_i64; *hi_f64 = (double)*hi_i64; }
+        return rc;
+    }
+    return orc_api_bound_stripe_pi_f64(m, n, N, pos, idx, K, Pi, mdl, lo_f64, hi_f64);
 }
 
 int32_t orc_objective(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,

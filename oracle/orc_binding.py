@@ -119,6 +119,13 @@ class OracleBackend:
             return rc, li.value, hi.value
         return rc, lf.value, hf.value
 
+    def bound_stripe_pi(self, A, K, rp, mm):
+        li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        rc = lib().orc_bound_stripe_pi(*self._A(A), _i64(K), C.byref(rp), mm.ptr, C.byref(li), C.byref(hi), C.byref(lf), C.byref(hf))
+        if mm.struct.dtype == 0:
+            return rc, li.value, hi.value
+        return rc, lf.value, hf.value
+
     def objective(self, A, K, spl, mm, rp, g):
         oi, of = C.c_int64(), C.c_double()
         rc = lib().orc_objective(*self._A(A), _i64(K), _p(spl), mm.ptr, C.byref(rp) if rp is not None else None,
