@@ -24,7 +24,7 @@ SYMBOLS = [
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
-    "cp_adjoint", "cp_csr_download",
+    "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi",
 ]
 
 _lib = None
@@ -181,6 +181,13 @@ class HipBackend:
     def bound_stripe(self, A, K, mm):
         li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         rc = self.lib.cp_bound_stripe(self._h(A), _i64(K), mm.ptr, C.byref(li), C.byref(hi), C.byref(lf), C.byref(hf))
+        if mm.struct.dtype == M.CP_I64:
+            return rc, li.value, hi.value
+        return rc, lf.value, hf.value
+
+    def bound_stripe_pi(self, A, K, rp, mm):
+        li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        rc = self.lib.cp_bound_stripe_pi(self._h(A), _i64(K), C.byref(rp), mm.ptr, C.byref(li), C.byref(hi), C.byref(lf), C.byref(hf))
         if mm.struct.dtype == M.CP_I64:
             return rc, li.value, hi.value
         return rc, lf.value, hf.value

@@ -97,7 +97,7 @@ static int32_t guarded(F &&f)
 
 static bool model_known(const cp_model_t *m)
 {
-    if (!m || m->kind < CP_MODEL_FEASIBLE || m->kind > CP_MODEL_POWER_WORK) return false;
+    if (!m || m->kind < CP_MODEL_FEASIBLE || m->kind > CP_MODEL_SECONDARY) return false;
     if (m->kind == CP_MODEL_POWER_WORK) return m->dtype == CP_F64;
     return m->dtype == CP_I64 || m->dtype == CP_F64;
 }
@@ -486,6 +486,11 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
         CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
         CP_HIP(hipSetDevice(A->device));
         bool constrained = weight && weight->kind != CP_MODEL_FEASIBLE;
+        if (model->kind == CP_MODEL_PRIMARY || model->kind == CP_MODEL_SECONDARY) {
+            CP_REQUIRE(!constrained, CP_EUNSUPPORTED, "ConstrainedCost over a plaid connectivity model has no device path");
+            if (model->dtype == CP_I64) return run_plaid_dynamic<int64_t>(A, K, combine, order, model, Pi, spl_out);
+            return run_plaid_dynamic<double>(A, K, combine, order, model, Pi, spl_out);
+        }
         if (constrained) {
             CP_REQUIRE(weight->kind == CP_MODEL_VERTEX_COUNT || (weight->kind == CP_MODEL_WORK && !weight->alpha_k), CP_EINVAL,
                        "weight must be VertexCount or an AffineWorkModel");
@@ -520,6 +525,10 @@ int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && model_known(model) && (nq == 0 || (j && jp)), CP_EINVAL, "bad argument");
         CP_HIP(hipSetDevice(A->device));
+        if (model->kind == CP_MODEL_PRIMARY || model->kind == CP_MODEL_SECONDARY) {
+            if (model->dtype == CP_I64) return run_plaid_eval<int64_t>(A, model, Pi, nq, j, jp, k, out_i64);
+            return run_plaid_eval<double>(A, model, Pi, nq, j, jp, k, out_f64);
+        }
         if (model->kind == CP_MODEL_BLOCK) {          // stateful step oracle: evaluated in query order by one wave (seq.hip)
             if (model->dtype == CP_I64) return run_seq_eval<int64_t>(A, model, Pi, nq, j, jp, k, out_i64);
             return run_seq_eval<double>(A, model, Pi, nq, j, jp, k, out_f64);
@@ -534,6 +543,18 @@ int32_t cp_objective(cp_csr_t A, int64_t K, const int64_t *spl, const cp_model_t
 {
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && spl && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        if (model->kind == CP_MODEL_SECONDARY) {
+            // SecondaryConnectivityCosts.jl:103-108: the primary objective of the adjoint with the two partitions swapped
+            CP_REQUIRE(Pi && Pi->spl && Pi->K == K, CP_EINVAL, "the secondary objective needs a SplitPartition Pi with K parts");
+            cp_csr_t T = nullptr;
+            int32_t rc = cp_adjoint(A, &T);
+            if (rc != CP_OK) return rc;
+            cp_model_t pm = *model; pm.kind = CP_MODEL_PRIMARY;
+            cp_rowpart_t rp; rp.K = K; rp.asg = nullptr; rp.spl = spl;
+            rc = cp_objective(T, K, Pi->spl, &pm, &rp, combine, out_i64, out_f64);
+            cp_csr_destroy(T);
+            return rc;
+        }
         std::vector<int64_t> j((size_t)K), jp((size_t)K), kk((size_t)K);
         for (int64_t k = 0; k < K; k++) { j[k] = spl[k]; jp[k] = spl[k + 1]; kk[k] = k + 1; }
         if (model->dtype == CP_I64) {
@@ -576,6 +597,20 @@ int32_t cp_bound_stripe(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t 
                 else { set_error("bound_stripe: mixed-sign work model"); return CP_EINVAL; }
             }
             return CP_OK;
+        }
+        if (model->kind == CP_MODEL_PRIMARY) {                                         // PrimaryConnectivityCosts.jl:43-51
+            bool neg = model->dtype == CP_I64 ? (model->p_i64[1] < 0 || model->p_i64[2] < 0 || model->p_i64[3] < 0 || model->p_i64[4] < 0)
+                                              : (model->p_f64[1] < 0 || model->p_f64[2] < 0 || model->p_f64[3] < 0 || model->p_f64[4] < 0);
+            CP_REQUIRE(!neg, CP_EINVAL, "bound_stripe asserts beta >= 0");
+            cp_model_t c = *model; c.kind = CP_MODEL_CONNECTIVITY; c.alpha_k = nullptr; c.n_alpha_k = 0;
+            int64_t di, dh; double df, dg;
+            if (model->dtype == CP_I64) { c.p_i64[CP_P_NET] = std::max(model->p_i64[3], model->p_i64[4]); c.p_i64[4] = 0; }
+            else { c.p_f64[CP_P_NET] = std::max(model->p_f64[3], model->p_f64[4]); c.p_f64[4] = 0; }
+            int32_t rc = cp_bound_stripe(A, K, &c, &di, hi_i64, &df, hi_f64);
+            if (rc != CP_OK) return rc;
+            if (model->dtype == CP_I64) c.p_i64[CP_P_NET] = std::min(model->p_i64[3], model->p_i64[4]);
+            else c.p_f64[CP_P_NET] = std::min(model->p_f64[3], model->p_f64[4]);
+            return cp_bound_stripe(A, K, &c, lo_i64, &dh, lo_f64, &dg);
         }
         if (model->kind == CP_MODEL_CONNECTIVITY && model->alpha_k && model->n_alpha_k > 0) {
             // per-part alpha = the reference tests' FunkyConnectivityModel; its bound_stripe (test_Partitioners.jl:36-41) is
@@ -623,6 +658,49 @@ int32_t cp_bound_stripe(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t 
         }
         set_error("bound_stripe has no method for this model (the reference raises MethodError)");
         return CP_EUNSUPPORTED;
+    });
+}
+
+// bound_stripe(A, K, Pi, mdl): Costs.jl:17-19 drops Pi for every model but the secondary one
+// (SecondaryConnectivityCosts.jl:21-31 == :42-61: per part of Pi, c_lo = max work cost, c_hi = max work cost + nets * b_remote)
+int32_t cp_bound_stripe_pi(cp_csr_t A, int64_t K, const cp_rowpart_t *Pi, const cp_model_t *model, int64_t *lo_i64, int64_t *hi_i64,
+                           double *lo_f64, double *hi_f64)
+{
+    if (!model || model->kind != CP_MODEL_SECONDARY) return cp_bound_stripe(A, K, model, lo_i64, hi_i64, lo_f64, hi_f64);
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && model_known(model) && K >= 1 && Pi && Pi->spl, CP_EINVAL, "bad argument");
+        bool neg = model->dtype == CP_I64 ? (model->p_i64[1] < 0 || model->p_i64[2] < 0 || model->p_i64[3] < 0 || model->p_i64[4] < 0)
+                                          : (model->p_f64[1] < 0 || model->p_f64[2] < 0 || model->p_f64[3] < 0 || model->p_f64[4] < 0);
+        CP_REQUIRE(!neg, CP_EINVAL, "bound_stripe asserts beta >= 0");
+        // the two bounds are the secondary cost with all nets local resp. all nets remote: evaluate the oracle on the empty and the
+        // full column range of every part with (b_local, b_remote) = (0, 0) resp. (b_remote, b_remote)
+        int64_t Kp = Pi->K;
+        std::vector<int64_t> one((size_t)Kp, 1), ks((size_t)Kp);
+        for (int64_t k = 0; k < Kp; k++) ks[(size_t)k] = k + 1;
+        cp_model_t lo_m = *model, hi_m = *model;
+        if (model->dtype == CP_I64) { lo_m.p_i64[3] = 0; lo_m.p_i64[4] = 0; hi_m.p_i64[3] = model->p_i64[4]; }
+        else { lo_m.p_f64[3] = 0; lo_m.p_f64[4] = 0; hi_m.p_f64[3] = model->p_f64[4]; }
+        lo_m.alpha_k = nullptr; lo_m.n_alpha_k = 0; hi_m.alpha_k = nullptr; hi_m.n_alpha_k = 0;
+        if (model->dtype == CP_I64) {
+            std::vector<int64_t> a((size_t)Kp), b((size_t)Kp);
+            int32_t rc = cp_oracle_eval(A, &lo_m, Pi, CP_HINT_STEP, Kp, one.data(), one.data(), ks.data(), a.data(), nullptr);
+            if (rc != CP_OK) return rc;
+            rc = cp_oracle_eval(A, &hi_m, Pi, CP_HINT_STEP, Kp, one.data(), one.data(), ks.data(), b.data(), nullptr);
+            if (rc != CP_OK) return rc;
+            int64_t clo = 0, chi = 0;                                  // "c_lo = 0; c_hi = 0" (:44-45)
+            for (int64_t k = 0; k < Kp; k++) { clo = std::max(clo, a[(size_t)k]); chi = std::max(chi, b[(size_t)k]); }
+            *lo_i64 = clo; *hi_i64 = chi; *lo_f64 = (double)clo; *hi_f64 = (double)chi;
+        } else {
+            std::vector<double> a((size_t)Kp), b((size_t)Kp);
+            int32_t rc = cp_oracle_eval(A, &lo_m, Pi, CP_HINT_STEP, Kp, one.data(), one.data(), ks.data(), nullptr, a.data());
+            if (rc != CP_OK) return rc;
+            rc = cp_oracle_eval(A, &hi_m, Pi, CP_HINT_STEP, Kp, one.data(), one.data(), ks.data(), nullptr, b.data());
+            if (rc != CP_OK) return rc;
+            double clo = 0, chi = 0;
+            for (int64_t k = 0; k < Kp; k++) { clo = std::max(clo, a[(size_t)k]); chi = std::max(chi, b[(size_t)k]); }
+            *lo_f64 = clo; *hi_f64 = chi;
+        }
+        return CP_OK;
     });
 }
 

@@ -26,6 +26,14 @@ template <typename TC>
 int32_t run_seq_eval(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int64_t *j, const int64_t *jp,
                      const int64_t *k, TC *out);
 
+// plaid.hip: primary / secondary connectivity costs (need a row partition)
+template <typename TC>
+int32_t run_plaid_eval(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int64_t *j, const int64_t *jp,
+                       const int64_t *k, TC *out);
+template <typename TC>
+int32_t run_plaid_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                          int64_t *spl_out);
+
 // chunk_scan.hip: DynamicTotalChunker under a VertexCount window as a (min,+) scan; false = not applicable
 template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);

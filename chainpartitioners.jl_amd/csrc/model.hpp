@@ -91,6 +91,9 @@ __device__ __forceinline__ TC dm_apply(const DevModel<TC> &m, TC alpha, int64_t 
         return (TC)nv;
     case CP_MODEL_POWER_WORK:
         return pw_apply(alpha, m.p, nv, np);
+    case CP_MODEL_PRIMARY: case CP_MODEL_SECONDARY:     // nn = local nets, nl = remote nets (PrimaryConnectivityCosts.jl:20)
+        return cadd(cadd(cadd(cadd(alpha, cmulc(nv, m.p[CP_P_VERTEX])), cmulc(np, m.p[CP_P_PIN])), cmulc(nn, m.p[CP_P_LOCAL_NET])),
+                    cmulc(nl, m.p[CP_P_REMOTE_NET]));
     default:
         return (TC)0;
     }

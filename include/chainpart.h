@@ -79,6 +79,9 @@ int32_t cp_oracle_eval(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t
 /* bound_stripe(A, K, mdl)  WorkCosts.jl:37-51, ConnectivityCosts.jl:22-35 */
 int32_t cp_bound_stripe(cp_csr_t csr, int64_t K, const cp_model_t *model,
                         int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);
+/* bound_stripe(A, K, Pi, mdl) (Costs.jl:17-19): Pi only matters to CP_MODEL_SECONDARY (SecondaryConnectivityCosts.jl:21-31) */
+int32_t cp_bound_stripe_pi(cp_csr_t csr, int64_t K, const cp_rowpart_t *Pi, const cp_model_t *model,
+                           int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);
 /* total_value / bottleneck_value  Costs.jl:26-66 */
 int32_t cp_objective(cp_csr_t csr, int64_t K, const int64_t *spl, const cp_model_t *model,
                      const cp_rowpart_t *Pi, int32_t combine, int64_t *out_i64, double *out_f64);
