@@ -14,9 +14,10 @@ from .models import (PowerWorkModel, ConvexWorkModel, ConcaveWorkModel,   # noqa
                      ReferenceTotalSplitter, ReferenceBottleneckSplitter, ReferenceTotalChunker,
                      BisectCostBottleneckSplitter, FlipBisectCostBottleneckSplitter,
                      BisectIndexBottleneckSplitter, FlipBisectIndexBottleneckSplitter,
-                     LazyBisectCostBottleneckSplitter,
+                     LazyBisectCostBottleneckSplitter, DisjointPartitioner, AlternatingPartitioner,
+                     AlternatingNetPartitioner, SymmetricPartitioner,
                      ConvexTotalChunker, ConvexTotalSplitter, ConcaveTotalChunker, ConcaveTotalSplitter)
 from . import _lib  # noqa: F401
-from .api import (adjointpattern, partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
+from .api import (adjointpattern, partition_plaid, partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
                   bottleneck_value, netcount, selfnetcount, dominancecount, set_default_backend,
                   get_backend, CPError)

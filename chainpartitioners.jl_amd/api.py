@@ -257,6 +257,37 @@ def bottleneck_value(A, Phi, mdl, Pi=None, *, backend=None):
     return _objective(M.CP_COMBINE_MAX, A, Phi, M.split_constraint(mdl)[0], Pi, backend)
 
 
+def partition_plaid(A: SparseMatrixCSC, K, method, *, adj_A=None, backend=None):
+    """partition_plaid(A, K, method) -> (Pi, Phi)  (AlternatingPartitioner.jl:6-87): the 2-D callers of partition_stripe.
+    A and its adjoint both stay resident on the device between the sweeps."""
+    K = int(K)
+    if isinstance(method, M.DisjointPartitioner):
+        Phi = partition_stripe(A, K, method.mtd, backend=backend)
+        T = adj_A if adj_A is not None else adjointpattern(A, backend=backend)
+        Pi = partition_stripe(T, K, method.mtd2, Phi, backend=backend)
+        return Pi, Phi
+    if isinstance(method, M.AlternatingPartitioner):            # also AlternatingNetPartitioner
+        T = adj_A if adj_A is not None else adjointpattern(A, backend=backend)
+        Phi = partition_stripe(A, K, method.mtds[0], backend=backend)
+        Pi = partition_stripe(T, K, method.mtds[1], Phi, backend=backend)
+        for i, mtd in enumerate(method.mtds[2:], start=1):
+            if i % 2 == 1:
+                Phi = partition_stripe(A, K, mtd, Pi, backend=backend)
+            else:
+                Pi = partition_stripe(T, K, mtd, Phi, backend=backend)
+        return Pi, Phi
+    if isinstance(method, M.SymmetricPartitioner):
+        if len(method.mtds) > 1:
+            T = adj_A if adj_A is not None else adjointpattern(A, backend=backend)
+            Pi = partition_stripe(A, K, method.mtds[0], backend=backend)
+            for i, mtd in enumerate(method.mtds[1:], start=1):
+                Pi = partition_stripe(A if i % 2 == 1 else T, K, mtd, Pi, backend=backend)
+        else:
+            Pi = partition_stripe(A, K, method.mtds[0], backend=backend)
+        return Pi, Pi
+    raise NotImplementedError(f"partition_plaid: method {type(method).__name__} is outside the hot path")
+
+
 def adjointpattern(A: SparseMatrixCSC, *, backend=None) -> SparseMatrixCSC:
     """adjointpattern(A) (util.jl:67-95): transposed pattern, computed on the device (cp_adjoint); the returned matrix
     keeps its device handle, so partitioning it needs no upload."""

@@ -419,6 +419,37 @@ class LazyBisectCostBottleneckSplitter:
         self.f, self.eps = f, float(eps)
 
 
+class DisjointPartitioner:
+    """AlternatingPartitioner.jl:1-10: columns first, then the rows of the adjoint given the column split."""
+
+    def __init__(self, mtd, mtd2):
+        self.mtd, self.mtd2 = mtd, mtd2
+
+
+class AlternatingPartitioner:
+    """AlternatingPartitioner.jl:12-32: Phi on A, Pi on the adjoint given Phi, then alternately again."""
+
+    def __init__(self, *mtds):
+        assert len(mtds) >= 2
+        self.mtds = tuple(mtds)
+
+
+class AlternatingNetPartitioner(AlternatingPartitioner):
+    """AlternatingPartitioner.jl:34-58: same sweeps, sharing one net counter of A (the device keeps A's link arrays anyway)."""
+
+    def __init__(self, *mtds, hint=None):
+        super().__init__(*mtds)
+        self.hint = hint
+
+
+class SymmetricPartitioner:
+    """AlternatingPartitioner.jl:60-87: one partition for rows and columns of a square matrix."""
+
+    def __init__(self, *mtds):
+        assert len(mtds) >= 1
+        self.mtds = tuple(mtds)
+
+
 class ConvexTotalChunker(_FMethod):
     pass
 

@@ -57,3 +57,33 @@ def test_dp_on_plaid_costs_matches_oracle(hip, orc):
                     got = cp.partition_stripe(adjA, K, meth(local), Phi, backend=hip)
                     want = cp.partition_stripe(adjA, K, meth(local), Phi, backend=orc)
                     assert got == want, (A, K, prm, meth.__name__, "secondary")
+
+
+def test_partition_plaid_alternating(hip, orc):
+    """partition_plaid with the reference benchmark's models (runbenchmarks.jl:16-20: net_model, comm_model, local_model):
+    the same (Pi, Phi) as the oracle, well-formed, and the later sweeps never make the communication bottleneck worse
+    than the first sweep left it for the partition they start from."""
+    rng = np.random.default_rng(82)
+    net = cp.AffineConnectivityModel(0, 10, 1, 100)
+    comm = cp.AffinePrimaryConnectivityModel(0, 10, 1, 0, 100)
+    local = cp.AffineSecondaryConnectivityModel(0, 10, 1, 0, 100)
+    for A in (sprand(30, 40, 0.1, rng), sprand(64, 64, 0.08, rng), suitesparse_shaped(500, 5, 9)):
+        for K in (2, 4):
+            for method in (cp.DisjointPartitioner(cp.DynamicBottleneckSplitter(net), cp.DynamicBottleneckSplitter(local)),
+                           cp.AlternatingPartitioner(cp.DynamicBottleneckSplitter(net), cp.DynamicBottleneckSplitter(local)),
+                           cp.AlternatingPartitioner(cp.DynamicBottleneckSplitter(net), cp.DynamicBottleneckSplitter(local),
+                                                     cp.DynamicBottleneckSplitter(comm), cp.DynamicBottleneckSplitter(local)),
+                           cp.AlternatingNetPartitioner(cp.DynamicTotalSplitter(net), cp.DynamicTotalSplitter(local), cp.DynamicTotalSplitter(comm))):
+                Pi, Phi = cp.partition_plaid(A, K, method, backend=hip)
+                Pi2, Phi2 = cp.partition_plaid(A, K, method, backend=orc)
+                assert Pi == Pi2 and Phi == Phi2
+                assert Pi.spl[0] == 1 and Pi.spl[-1] == A.m + 1 and Phi.spl[0] == 1 and Phi.spl[-1] == A.n + 1
+                assert np.all(np.diff(Pi.spl) >= 0) and np.all(np.diff(Phi.spl) >= 0)
+    # a sweep with the primary model given Pi is optimal for that Pi: no worse than the columns it started from
+    A = suitesparse_shaped(500, 5, 9); K = 4
+    Pi, Phi0 = cp.partition_plaid(A, K, cp.AlternatingPartitioner(cp.DynamicBottleneckSplitter(net), cp.DynamicBottleneckSplitter(local)), backend=hip)
+    Phi1 = cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(comm), Pi, backend=hip)
+    assert cp.bottleneck_value(A, Phi1, comm, Pi, backend=hip) <= cp.bottleneck_value(A, Phi0, comm, Pi, backend=hip)
+    if A.m == A.n:
+        P, P2 = cp.partition_plaid(A, K, cp.SymmetricPartitioner(cp.DynamicBottleneckSplitter(net)), backend=hip)
+        assert P == P2 == cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(net), backend=orc)
