@@ -24,7 +24,7 @@ SYMBOLS = [
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
-    "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi",
+    "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
 ]
 
 _lib = None
@@ -146,11 +146,13 @@ class HipBackend:
         return self.lib.cp_pack_dynamic(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,
                                         wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
 
-    def partition_bisect_cost(self, A, K, mm, eps, flip, spl):
-        return self.lib.cp_partition_bisect_cost(self._h(A), _i64(K), mm.ptr, C.c_double(eps), C.c_int32(flip), _p(spl))
+    def partition_bisect_cost(self, A, K, mm, eps, flip, spl, rp=None):
+        return self.lib.cp_partition_bisect_cost_pi(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
+                                                    C.c_double(eps), C.c_int32(flip), _p(spl))
 
-    def partition_bisect_index(self, A, K, mm, flip, spl):
-        return self.lib.cp_partition_bisect_index(self._h(A), _i64(K), mm.ptr, C.c_int32(flip), _p(spl))
+    def partition_bisect_index(self, A, K, mm, flip, spl, rp=None):
+        return self.lib.cp_partition_bisect_index_pi(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
+                                                     C.c_int32(flip), _p(spl))
 
     def partition_lazy_bisect_cost(self, A, K, mm, eps, spl):
         return self.lib.cp_partition_lazy_bisect_cost(self._h(A), _i64(K), mm.ptr, C.c_double(eps), _p(spl))

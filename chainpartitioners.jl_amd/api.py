@@ -132,19 +132,19 @@ def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) ->
         _check(rc, "partition_stripe(Dynamic*)", b)
         return SplitPartition(K, spl)
     if isinstance(method, M.BisectCostBottleneckSplitter):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, None)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi if getattr(M.split_constraint(method.f)[0], "needs_rowpart", False) else None)
         if wm is not None:
             raise NotImplementedError("BisectCost on a ConstrainedCost errors in the reference (Costs.jl:150)")
         spl = np.zeros(K + 1, dtype=np.int64)
-        rc = b.partition_bisect_cost(A, K, mm, method.eps, method.flip, spl)
+        rc = b.partition_bisect_cost(A, K, mm, method.eps, method.flip, spl, rp)
         _check(rc, "partition_stripe(BisectCost)", b)
         return SplitPartition(K, spl)
     if isinstance(method, M.BisectIndexBottleneckSplitter):
-        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, None)
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, method.f, Pi if getattr(M.split_constraint(method.f)[0], "needs_rowpart", False) else None)
         if wm is not None:
             raise NotImplementedError("BisectIndex on a ConstrainedCost errors in the reference (Costs.jl:150)")
         spl = np.zeros(K + 1, dtype=np.int64)
-        rc = b.partition_bisect_index(A, K, mm, method.flip, spl)
+        rc = b.partition_bisect_index(A, K, mm, method.flip, spl, rp)
         _check(rc, "partition_stripe(BisectIndex)", b)
         return SplitPartition(K, spl)
     if isinstance(method, M.LazyBisectCostBottleneckSplitter):

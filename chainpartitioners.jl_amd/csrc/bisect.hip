@@ -42,15 +42,43 @@ struct OracleDev {
     int64_t n;
     int32_t has_net;
     WaveletDev net;
+    // plaid connectivity costs: 0 none, 1 primary, 2 secondary.  partwise(A, Pi) (PartwiseCounts.jl:1-60):
+    // pios (K+1) / prm (n') hold 1-based values as the reference does; primary adds the net counter of the partwise matrix
+    int32_t plaid;
+    const int64_t *pios, *prm;
+    WaveletDev lcn; int64_t np; const int64_t *ppos;
+    const int64_t *spl, *tpos;            // secondary: the row split (1-based) and the row pointer of A (0-based)
 };
+
+// PartwiseCount rank: pios[k] + searchsortedfirst(prm[pios[k] : pios[k+1]-1], j) - 1   (PartwiseCounts.jl:86-88)
+template <typename TC>
+__device__ __forceinline__ int64_t pw_rank(const OracleDev<TC> &O, int64_t j, int64_t k)
+{
+    int64_t lo = O.pios[k - 1], hi = O.pios[k];       // 1-based positions into prm
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (O.prm[mid - 1] < j) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 template <typename TC>
 __device__ __forceinline__ TC oracle_eval_dev(const OracleDev<TC> &O, int64_t j, int64_t jp, int64_t k)
 {
     int64_t p = j - 1, r = jp - 1;
+    if (O.plaid == 2) {                                                   // SecondaryConnectivityCosts.jl:79-86
+        int64_t l = pw_rank(O, jp, k) - pw_rank(O, j, k);
+        int64_t s0 = O.spl[k - 1] - 1, s1 = O.spl[k] - 1;
+        return dm_apply(O.M, dm_alpha(O.M, k), s1 - s0, O.tpos[s1] - O.tpos[s0], l, (O.pios[k] - O.pios[k - 1]) - l);
+    }
     int64_t np = O.pos[r] - O.pos[p];
     int64_t nn = 0;
     if (O.has_net) nn = np - wt_count_le(O.net, O.n - p, O.pos[r]);      // SparseColorArrays.jl:121-125
+    if (O.plaid == 1) {                                                   // PrimaryConnectivityCosts.jl:67-74
+        int64_t pj = pw_rank(O, j, k) - 1, pr = pw_rank(O, jp, k) - 1;    // columns of the partwise matrix, 0-based
+        int64_t l = (O.ppos[pr] - O.ppos[pj]) - wt_count_le(O.lcn, O.np - pj, O.ppos[pr]);
+        return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, l, nn - l);
+    }
     return dm_apply(O.M, dm_alpha(O.M, k), r - p, np, nn, (int64_t)0);
 }
 
@@ -222,17 +250,51 @@ __global__ void __launch_bounds__(64) k_bisect_index(OracleDev<TC> O, int64_t K,
     if (lane == 0) *nprobes = probes;
 }
 
+struct CsrGuard { cp_csr_t h = nullptr; ~CsrGuard() { if (h) cp_csr_destroy(h); } };
+
 template <typename TC>
-int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, double c_hi, double eps, int flip, int64_t *spl_out,
-                   bool by_index = false)
+int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, double c_lo, double c_hi, double eps, int flip,
+                   int64_t *spl_out, bool by_index = false)
 {
     hipStream_t s = A->stream;
     HostModel<TC> HM;
     build_dev_model<TC>(mdl, HM, s);
     OracleDev<TC> O;
+    memset(&O, 0, sizeof(O));
     O.M = HM.d; O.pos = A->pos.p; O.n = A->n; O.has_net = 0;
-    WaveletHost net;
-    if (mdl->kind == CP_MODEL_CONNECTIVITY) { ensure_net_counter(A, net); O.has_net = 1; O.net = net.d; }
+    WaveletHost net, lcn;
+    CsrGuard Ap;
+    DBuf<int64_t> d_pios, d_prm, d_spl2;
+    if (mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_PRIMARY) { ensure_net_counter(A, net); O.has_net = 1; O.net = net.d; }
+    if (mdl->kind == CP_MODEL_PRIMARY || mdl->kind == CP_MODEL_SECONDARY) {
+        bool sec = mdl->kind == CP_MODEL_SECONDARY;
+        CP_REQUIRE(Pi && (Pi->asg || Pi->spl) && Pi->K >= 1, CP_EINVAL, "this cost model needs a row partition Pi");
+        CP_REQUIRE(!sec || (Pi->spl && K <= Pi->K), CP_EINVAL, "the secondary connectivity model needs a SplitPartition of the rows with >= K parts");
+        int64_t m = A->m, N = A->N, Kp = Pi->K;
+        std::vector<int64_t> asg((size_t)(m > 0 ? m : 1), 1);
+        if (Pi->asg) for (int64_t i = 0; i < m; i++) asg[(size_t)i] = Pi->asg[i];
+        else for (int64_t k = 1; k <= Kp; k++) for (int64_t i = Pi->spl[k - 1]; i <= Pi->spl[k] - 1; i++) { CP_REQUIRE(i >= 1 && i <= m, CP_EINVAL, "split vector out of range"); asg[(size_t)i - 1] = k; }
+        std::vector<int64_t> pios((size_t)Kp + 1), prm((size_t)(N > 0 ? N : 1)), ppos((size_t)N + 2), pidx((size_t)(N > 0 ? N : 1));
+        int64_t npr = 0;
+        int32_t rc = cp_partwise(A, Kp, asg.data(), &npr, pios.data(), prm.data(), ppos.data(), pidx.data());
+        if (rc != CP_OK) return rc;
+        d_pios.alloc((size_t)Kp + 1); d_prm.alloc((size_t)(npr > 0 ? npr : 1));
+        CP_HIP(hipMemcpyAsync(d_pios.p, pios.data(), sizeof(int64_t) * (size_t)(Kp + 1), hipMemcpyHostToDevice, s));
+        if (npr > 0) CP_HIP(hipMemcpyAsync(d_prm.p, prm.data(), sizeof(int64_t) * (size_t)npr, hipMemcpyHostToDevice, s));
+        O.plaid = sec ? 2 : 1; O.pios = d_pios.p; O.prm = d_prm.p;
+        if (!sec) {
+            rc = cp_csr_create(m, npr, N, ppos.data(), pidx.data(), A->device, &Ap.h);          // the partwise matrix and its net counter
+            if (rc != CP_OK) return rc;
+            ensure_net_counter(Ap.h, lcn);
+            O.lcn = lcn.d; O.np = npr; O.ppos = Ap.h->pos.p;
+        } else {
+            d_spl2.alloc((size_t)Kp + 1);
+            CP_HIP(hipMemcpyAsync(d_spl2.p, Pi->spl, sizeof(int64_t) * (size_t)(Kp + 1), hipMemcpyHostToDevice, s));
+            ensure_links(A);
+            O.spl = d_spl2.p; O.tpos = A->tpos.p;
+        }
+        CP_HIP(hipStreamSynchronize(s));              // host staging vectors die at scope end
+    }
     DBuf<int64_t> buf((size_t)(4 * (K + 1) + 1));
     int64_t *d_lo = buf.p, *d_hi = buf.p + (K + 1), *d_spl = buf.p + 2 * (K + 1), *d_out = buf.p + 3 * (K + 1), *d_np = buf.p + 4 * (K + 1);
     {
@@ -254,29 +316,41 @@ int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, double c_lo, d
 
 using namespace cpk;
 
-extern "C" int32_t cp_partition_bisect_cost(cp_csr_t A, int64_t K, const cp_model_t *model, double eps, int32_t flip, int64_t *spl_out)
+extern "C" int32_t cp_partition_bisect_cost_pi(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, double eps,
+                                               int32_t flip, int64_t *spl_out)
 {
     try {
         CP_REQUIRE(A && model && spl_out && K >= 1, CP_EINVAL, "bad argument");
         CP_HIP(hipSetDevice(A->device));
         int64_t li, hi; double lf, hf;
-        int32_t rc = cp_bound_stripe(A, K, model, &li, &hi, &lf, &hf);        // (c_lo, c_hi) = bound_stripe(...) ./ 1  (:39)
+        int32_t rc = cp_bound_stripe_pi(A, K, Pi, model, &li, &hi, &lf, &hf);    // (c_lo, c_hi) = bound_stripe(A, K, args..., f) ./ 1  (:39)
         if (rc != CP_OK) return rc;
-        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, lf, hf, eps, flip, spl_out);
-        return run_bisect<double>(A, K, model, lf, hf, eps, flip, spl_out);
+        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, Pi, lf, hf, eps, flip, spl_out);
+        return run_bisect<double>(A, K, model, Pi, lf, hf, eps, flip, spl_out);
     } catch (const HipFail &e) { return e.code; }
 }
 
+extern "C" int32_t cp_partition_bisect_cost(cp_csr_t A, int64_t K, const cp_model_t *model, double eps, int32_t flip, int64_t *spl_out)
+{
+    return cp_partition_bisect_cost_pi(A, K, model, nullptr, eps, flip, spl_out);
+}
+
 // partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f))  BisectIndexBottleneckSplitter.jl:5-166
-extern "C" int32_t cp_partition_bisect_index(cp_csr_t A, int64_t K, const cp_model_t *model, int32_t flip, int64_t *spl_out)
+extern "C" int32_t cp_partition_bisect_index_pi(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t flip,
+                                                int64_t *spl_out)
 {
     try {
         CP_REQUIRE(A && model && spl_out && K >= 1, CP_EINVAL, "bad argument");
         CP_HIP(hipSetDevice(A->device));
         int64_t li, hi; double lf, hf;
-        int32_t rc = cp_bound_stripe(A, K, model, &li, &hi, &lf, &hf);        // (c_lo, c_hi) = bound_stripe(...) ./ 1  (:39)
+        int32_t rc = cp_bound_stripe_pi(A, K, Pi, model, &li, &hi, &lf, &hf);    // (c_lo, c_hi) = bound_stripe(...) ./ 1  (:39)
         if (rc != CP_OK) return rc;
-        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, lf, hf, 0.0, flip, spl_out, true);
-        return run_bisect<double>(A, K, model, lf, hf, 0.0, flip, spl_out, true);
+        if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, Pi, lf, hf, 0.0, flip, spl_out, true);
+        return run_bisect<double>(A, K, model, Pi, lf, hf, 0.0, flip, spl_out, true);
     } catch (const HipFail &e) { return e.code; }
+}
+
+extern "C" int32_t cp_partition_bisect_index(cp_csr_t A, int64_t K, const cp_model_t *model, int32_t flip, int64_t *spl_out)
+{
+    return cp_partition_bisect_index_pi(A, K, model, nullptr, flip, spl_out);
 }

@@ -101,6 +101,12 @@ int32_t cp_pack_dynamic(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_
 /* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))  BisectCostBottleneckSplitter.jl:6-127 */
 int32_t cp_partition_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
                                  int32_t flip, int64_t *spl_out /* K+1 */);
+/* the same two with the row partition the plaid cost models need: partition_stripe(A, K, method, Pi)
+ * (CP_MODEL_PRIMARY / CP_MODEL_SECONDARY; Pi is ignored by every other model, Costs.jl:5-7) */
+int32_t cp_partition_bisect_cost_pi(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, double eps,
+                                    int32_t flip, int64_t *spl_out /* K+1 */);
+int32_t cp_partition_bisect_index_pi(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t flip,
+                                     int64_t *spl_out /* K+1 */);
 /* pack_stripe(A, ConcaveTotalChunker(f | ConstrainedCost(f,w,w_max)), [Pi]) ConcaveTotalChunker.jl:9-24, chunk_concave! :57-114;
  * partition_stripe(A, K, ConcaveTotalSplitter(..), [Pi]) :26-55 and the ConstrainedCost method :140-180.
  * The candidate-deque algorithm is exact for concave (Monge) costs, e.g. CP_MODEL_POWER_WORK with gamma >= 1. */

@@ -101,12 +101,12 @@ int32_t orc_pack_dynamic(int64_t m, int64_t n, int64_t N, const int64_t *pos, co
 
 /* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps)) BisectCostBottleneckSplitter.jl:6-127 */
 int32_t orc_partition_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
-                                  int64_t K, const cp_model_t *mdl, double eps, int32_t flip,
-                                  int64_t *spl_out, int64_t *n_probes_out);
+                                  int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi /* NULL unless the model needs it */,
+                                  double eps, int32_t flip, int64_t *spl_out, int64_t *n_probes_out);
 
 /* partition_stripe(A, K, [Flip]BisectIndexBottleneckSplitter(f)) BisectIndexBottleneckSplitter.jl:5-166 */
 int32_t orc_partition_bisect_index(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
-                                   int64_t K, const cp_model_t *mdl, int32_t flip,
+                                   int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, int32_t flip,
                                    int64_t *spl_out, int64_t *n_probes_out);
 
 /* partition_stripe(A, K, LazyBisectCostBottleneckSplitter(f::AbstractConnectivityModel, eps))

@@ -27,8 +27,8 @@
                                     const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, \
                                     double, int64_t *, int64_t *);                                         \
     int32_t orc_api_partition_bisect_cost##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,  \
-                                             int64_t, const cp_model_t *, double, int32_t, int64_t *,      \
-                                             int64_t *);                                                   \
+                                             int64_t, const cp_model_t *, const cp_rowpart_t *, double,    \
+                                             int32_t, int64_t *, int64_t *);                                                   \
     int32_t orc_api_pack_convex##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,            \
                                    const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t,  \
                                    double, int64_t *, int64_t *);                                          \
@@ -42,7 +42,8 @@
                                          int64_t, const cp_model_t *, const cp_rowpart_t *,                \
                                          const cp_model_t *, int64_t, double, int64_t *);                  \
     int32_t orc_api_partition_bisect_index##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, \
-                                              int64_t, const cp_model_t *, int32_t, int64_t *, int64_t *); \
+                                              int64_t, const cp_model_t *, const cp_rowpart_t *, int32_t,  \
+                                              int64_t *, int64_t *);                                       \
     int32_t orc_api_partition_lazy_bisect_cost##S(int64_t, int64_t, int64_t, const int64_t *,              \
                                                   const int64_t *, int64_t, const cp_model_t *, double,    \
                                                   int64_t *, int64_t *);
@@ -119,11 +120,11 @@ int32_t orc_pack_dynamic(int64_t m, int64_t n, int64_t N, const int64_t *pos, co
 }
 
 int32_t orc_partition_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
-                                  int64_t K, const cp_model_t *mdl, double eps, int32_t flip,
+                                  int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, double eps, int32_t flip,
                                   int64_t *spl_out, int64_t *n_probes_out)
 {
-    return IS_I(mdl) ? orc_api_partition_bisect_cost_i64(m, n, N, pos, idx, K, mdl, eps, flip, spl_out, n_probes_out)
-                     : orc_api_partition_bisect_cost_f64(m, n, N, pos, idx, K, mdl, eps, flip, spl_out, n_probes_out);
+    return IS_I(mdl) ? orc_api_partition_bisect_cost_i64(m, n, N, pos, idx, K, mdl, Pi, eps, flip, spl_out, n_probes_out)
+                     : orc_api_partition_bisect_cost_f64(m, n, N, pos, idx, K, mdl, Pi, eps, flip, spl_out, n_probes_out);
 }
 
 int32_t orc_pack_convex(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
@@ -144,10 +145,11 @@ int32_t orc_partition_convex(int64_t m, int64_t n, int64_t N, const int64_t *pos
 }
 
 int32_t orc_partition_bisect_index(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
-                                   int64_t K, const cp_model_t *mdl, int32_t flip, int64_t *spl_out, int64_t *n_probes_out)
+                                   int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, int32_t flip, int64_t *spl_out,
+                                   int64_t *n_probes_out)
 {
-    return IS_I(mdl) ? orc_api_partition_bisect_index_i64(m, n, N, pos, idx, K, mdl, flip, spl_out, n_probes_out)
-                     : orc_api_partition_bisect_index_f64(m, n, N, pos, idx, K, mdl, flip, spl_out, n_probes_out);
+    return IS_I(mdl) ? orc_api_partition_bisect_index_i64(m, n, N, pos, idx, K, mdl, Pi, flip, spl_out, n_probes_out)
+                     : orc_api_partition_bisect_index_f64(m, n, N, pos, idx, K, mdl, Pi, flip, spl_out, n_probes_out);
 }
 
 int32_t orc_partition_lazy_bisect_cost(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,

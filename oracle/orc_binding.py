@@ -71,9 +71,10 @@ class OracleBackend:
         pos = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int64)
         return type(A)(n, m, pos, cols[order])
 
-    def partition_bisect_index(self, A, K, mm, flip, spl):
+    def partition_bisect_index(self, A, K, mm, flip, spl, rp=None):
         pr = np.zeros(1, dtype=np.int64)
-        rc = lib().orc_partition_bisect_index(*self._A(A), _i64(K), mm.ptr, C.c_int32(flip), _p(spl), _p(pr))
+        rc = lib().orc_partition_bisect_index(*self._A(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None, C.c_int32(flip),
+                                              _p(spl), _p(pr))
         self.last_probes = int(pr[0])
         return rc
 
@@ -83,10 +84,10 @@ class OracleBackend:
         self.last_probes = int(pr[0])
         return rc
 
-    def partition_bisect_cost(self, A, K, mm, eps, flip, spl, probes=None):
+    def partition_bisect_cost(self, A, K, mm, eps, flip, spl, rp=None):
         pr = np.zeros(1, dtype=np.int64)
-        rc = lib().orc_partition_bisect_cost(*self._A(A), _i64(K), mm.ptr, C.c_double(eps), C.c_int32(flip),
-                                             _p(spl), _p(pr))
+        rc = lib().orc_partition_bisect_cost(*self._A(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None, C.c_double(eps),
+                                             C.c_int32(flip), _p(spl), _p(pr))
         self.last_probes = int(pr[0])
         return rc
 

@@ -87,3 +87,28 @@ def test_partition_plaid_alternating(hip, orc):
     if A.m == A.n:
         P, P2 = cp.partition_plaid(A, K, cp.SymmetricPartitioner(cp.DynamicBottleneckSplitter(net)), backend=hip)
         assert P == P2 == cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(net), backend=orc)
+
+
+def test_bisect_methods_on_plaid_costs_match_oracle(hip, orc):
+    """BisectCost / BisectIndex (+Flip) with the primary model given Pi and the secondary model on the adjoint given Phi --
+    the scalable methods of the reference's 2-D benchmark (runbenchmarks.jl:65-78): bit-exact split vectors."""
+    rng = np.random.default_rng(83)
+    mats = [sprand(m, n, p, rng) for (m, n, p) in ((3, 5, 0.4), (8, 8, 0.3), (20, 33, 0.15), (64, 70, 0.08))] + [suitesparse_shaped(3000, 6, 5)]
+    for A in mats:
+        adjA = cp.adjointpattern(A, backend=hip)
+        for K in (1, 2, 4, 7):
+            Pi = cp.partition_stripe(adjA, K, cp.EquiSplitter()); Phi = cp.partition_stripe(A, K, cp.EquiSplitter())
+            Pm = cp.MapPartition(K, (np.arange(A.m) % K) + 1)                     # runbenchmarks.jl:67: mod1.(1:m, K)
+            for prm in ((0, 10, 1, 0, 100), (0, 2, 1, 3, 6), (0.5, 1.0, 1.0, 2.0, 4.0)):
+                comm = cp.AffinePrimaryConnectivityModel(*prm); local = cp.AffineSecondaryConnectivityModel(*prm)
+                for P in (Pi, Pm):
+                    for meth in (cp.BisectCostBottleneckSplitter(comm, 0.01), cp.BisectIndexBottleneckSplitter(comm),
+                                 cp.FlipBisectIndexBottleneckSplitter(comm)):
+                        got = cp.partition_stripe(A, K, meth, P, backend=hip)
+                        want = cp.partition_stripe(A, K, meth, P, backend=orc)
+                        assert got == want, (A, K, prm, type(meth).__name__, type(P).__name__)
+                for meth in (cp.FlipBisectCostBottleneckSplitter(local, 0.01), cp.FlipBisectIndexBottleneckSplitter(local),
+                             cp.BisectIndexBottleneckSplitter(local)):
+                    got = cp.partition_stripe(adjA, K, meth, Phi, backend=hip)
+                    want = cp.partition_stripe(adjA, K, meth, Phi, backend=orc)
+                    assert got == want, (A, K, prm, type(meth).__name__, "secondary")

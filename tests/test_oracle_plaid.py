@@ -75,3 +75,55 @@ def test_dp_on_primary_and_secondary_costs(orc):
                     v = max(vals) if g == "max" else sum(vals)
                     best = v if best is None or v < best else best
                 assert val(A, got, comm, Pi, backend=orc) == best
+
+
+def test_bisect_methods_on_plaid_costs(orc):
+    """test_Partitioners.jl:76-113 with the primary model given Pi = EquiSplitter on the adjoint: BisectIndex is exact,
+    BisectCost within (1 + eps) of the DP optimum; the secondary model likewise on the adjoint."""
+    rng = np.random.default_rng(72)
+    for (m, n) in ((8, 8), (12, 20), (30, 25), (64, 64)):
+        A = sprand(m, n, 0.15, rng)
+        adjA = cp.adjointpattern(A, backend=orc)
+        for K in (1, 2, 3, 4):
+            Pi = cp.partition_stripe(adjA, K, cp.EquiSplitter())
+            Phi = cp.partition_stripe(A, K, cp.EquiSplitter())
+            for f, X, P in ((cp.AffinePrimaryConnectivityModel(0, 2, 1, 3, 6), A, Pi), (cp.AffineSecondaryConnectivityModel(0, 2, 1, 3, 6), adjA, Phi)):
+                ref = cp.partition_stripe(X, K, cp.DynamicBottleneckSplitter(f), P, backend=orc)
+                c = cp.bottleneck_value(X, ref, f, P, backend=orc) if isinstance(f, cp.AffineSecondaryConnectivityModel) is False else None
+                if isinstance(f, cp.AffineSecondaryConnectivityModel):
+                    ocl = cp.oracle_stripe(cp.StepHint(), f, X, P, backend=orc)
+                    val = lambda S: max(ocl(int(S.spl[k - 1]), int(S.spl[k]), k) for k in range(1, K + 1))
+                else:
+                    val = lambda S: cp.bottleneck_value(X, S, f, P, backend=orc)
+                c = val(ref)
+                got = cp.partition_stripe(X, K, cp.BisectIndexBottleneckSplitter(f), P, backend=orc)
+                assert got.spl[0] == 1 and got.spl[-1] == X.n + 1 and np.all(np.diff(got.spl) >= 0)
+                if isinstance(f, cp.AffinePrimaryConnectivityModel) and not isinstance(f, cp.AffineSecondaryConnectivityModel):
+                    assert val(got) == c
+                for eps in (0.1, 0.01):
+                    if isinstance(f, cp.AffineSecondaryConnectivityModel):
+                        continue            # decreasing in the range: the reference pairs it with the Flip variants
+                    got = cp.partition_stripe(X, K, cp.BisectCostBottleneckSplitter(f, eps), P, backend=orc)
+                    assert val(got) <= c * (1 + eps)
+
+
+def test_flip_bisect_on_the_secondary_cost(orc):
+    """test_Partitioners.jl:116-152: the secondary connectivity cost decreases with the range (more nets become local), so it
+    goes with the Flip variants: FlipBisectIndex is exact, FlipBisectCost within (1 + eps)."""
+    rng = np.random.default_rng(73)
+    f = cp.AffineSecondaryConnectivityModel(0, 2, 1, 3, 6)
+    for (m, n) in ((8, 8), (12, 20), (30, 25), (64, 64)):
+        A = sprand(m, n, 0.15, rng)
+        adjA = cp.adjointpattern(A, backend=orc)
+        for K in (1, 2, 3, 4):
+            Phi = cp.partition_stripe(A, K, cp.EquiSplitter())
+            ocl = cp.oracle_stripe(cp.StepHint(), f, adjA, Phi, backend=orc)
+            val = lambda S: max(ocl(int(S.spl[k - 1]), int(S.spl[k]), k) for k in range(1, K + 1))
+            ref = cp.partition_stripe(adjA, K, cp.DynamicBottleneckSplitter(f), Phi, backend=orc)
+            c = val(ref)
+            got = cp.partition_stripe(adjA, K, cp.FlipBisectIndexBottleneckSplitter(f), Phi, backend=orc)
+            assert got.spl[0] == 1 and got.spl[-1] == adjA.n + 1 and np.all(np.diff(got.spl) >= 0)
+            assert val(got) == c
+            for eps in (0.1, 0.01):
+                got = cp.partition_stripe(adjA, K, cp.FlipBisectCostBottleneckSplitter(f, eps), Phi, backend=orc)
+                assert val(got) <= c * (1 + eps)
