@@ -184,10 +184,13 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = (1 if tiled else world) * args.steps / dt
-        ex = prof["dp_lpass"]
+        # the dominant kernel: the left-part pass over the long tasks with tiles of their own (k_lpass_own) -- or, if it ever
+        # took longer, the pass over the flattened medium tasks (k_lpass)
+        dom, kname = max((("dp_lpass_own", "k_lpass_own"), ("dp_lpass", "k_lpass")), key=lambda kv: prof.get(kv[0], {"ms": 0.0})["ms"])
+        ex = prof[dom]
         avg_deg = N / n
-        # algorithmic bytes of one k_lpass launch, accumulated by the library per launch:
-        # per flattened left step the stepped column's link entries (4 B x N/n), its colptr entry (8 B), the
+        # algorithmic bytes of one launch, accumulated by the library per launch:
+        # per left step the stepped column's link entries (4 B x N/n), its colptr entry (8 B), the
         # candidate's previous-layer cost (8 B) and the task-descriptor share (8 B)
         bytes_per_launch = ex["units"] / max(ex["launches"], 1)
         avg_ms = ex["ms"] / max(ex["launches"], 1)
@@ -196,7 +199,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC counters: collected by tools/pmc_lpass.sh under rocprofv3
         # (FETCH_SIZE and WRITE_SIZE in separate passes) and committed under profiles/; valid for the default workload only
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc_k_lpass.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01d_pmc_%s.json" % kname)
         if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
             traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
         out = {
@@ -208,7 +211,7 @@ def main():
             "config": {"workload": "DynamicSplitter + %s on suitesparse_shaped CSR, "
                                    "n=%d rows, nnz=%d, K=%d; %s" % ("ConnectivityCosts (lambda-1)" if args.model == "connectivity" else "HyperedgeCutCosts (cut nets)", n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
                        "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
-            "roofline": {"bound": "hbm", "kernel": "dp_lpass (k_lpass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "%s (%s)" % (dom, kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": ex["launches"] / args.steps,
                          "alg_bytes_per_launch": bytes_per_launch,

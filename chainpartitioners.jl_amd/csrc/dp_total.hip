@@ -279,12 +279,15 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       const int32_t *__restrict__ fpos32, const int32_t *__restrict__ flast,
                                                       const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                       int4 *__restrict__ tdesc, uint8_t *__restrict__ tb, int32_t *__restrict__ len,
-                                                      int32_t *__restrict__ tS0l, int32_t *__restrict__ nlong, int32_t SHORT_T, int32_t SHORT_E)
+                                                      int32_t *__restrict__ tS0l, int32_t *__restrict__ nlong, int32_t SHORT_T, int32_t SHORT_E,
+                                                      int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
+                                                      int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
+                                                      unsigned long long *__restrict__ own_steps)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
     bool live = t < R.ntask;
-    bool is_long = false;
+    bool is_long = false, is_own = false;
     int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
     if (live) {
         decode_task(R, t, r, b);
@@ -323,29 +326,52 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                 }
                 opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
             }
+        } else if (o_tdesc && L >= LT) {
+            is_own = true;                           // long enough for tiles of its own (k_lpass_own): every tile is uniform
         } else {
             is_long = true;
         }
     }
-    // append the long tasks: ONE atomic per 1024-lane block (same-address atomics serialise in L2), order kept inside the block
-    __shared__ int32_t s_wcnt[16];
-    __shared__ int32_t s_base;
-    unsigned long long ml = __ballot(is_long);
+    // append the remaining tasks to their list -- the flattened one, or the one of tasks with tiles of their own: ONE atomic per
+    // list and 1024-lane block (same-address atomics serialise in L2), order kept inside the block
+    __shared__ int32_t s_wcnt[2][16];
+    __shared__ unsigned long long s_wsteps[16];
+    __shared__ int32_t s_base[2];
+    unsigned long long ml = __ballot(is_long), mo = __ballot(is_own);
     int wv = threadIdx.x >> 6;
-    if (lane == 0) s_wcnt[wv] = (int32_t)__popcll(ml);
+    int64_t Lmine = is_own ? 1 + (B - a) : 0;
+    unsigned long long lsum = 0;
+    if (mo) {                                                        // wave-uniform
+        lsum = (unsigned long long)Lmine;
+        for (int o = 32; o > 0; o >>= 1) lsum += ((unsigned long long)(uint32_t)__shfl_down((int)(lsum >> 32), o) << 32) | (uint32_t)__shfl_down((int)(lsum & 0xffffffffull), o);
+    }
+    if (lane == 0) { s_wcnt[0][wv] = (int32_t)__popcll(ml); s_wcnt[1][wv] = (int32_t)__popcll(mo); s_wsteps[wv] = lsum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int32_t tot = 0;
-        for (int w = 0; w < 16; w++) { int32_t c = s_wcnt[w]; s_wcnt[w] = tot; tot += c; }
-        s_base = tot ? atomicAdd(nlong, tot) : 0;
+        int32_t t0 = 0, t1 = 0; unsigned long long st = 0;
+        for (int w = 0; w < 16; w++) {
+            int32_t c0 = s_wcnt[0][w], c1 = s_wcnt[1][w];
+            s_wcnt[0][w] = t0; s_wcnt[1][w] = t1; t0 += c0; t1 += c1; st += s_wsteps[w];
+        }
+        s_base[0] = t0 ? atomicAdd(nlong, t0) : 0;
+        s_base[1] = t1 ? atomicAdd(n_own, t1) : 0;
+        if (st) atomicAdd(own_steps, st);
     }
     __syncthreads();
     if (is_long) {
-        int32_t idx = s_base + s_wcnt[wv] + __popcll(ml & ((1ull << lane) - 1ull));
+        int32_t idx = s_base[0] + s_wcnt[0][wv] + __popcll(ml & ((1ull << lane) - 1ull));
         tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
         tb[idx] = (uint8_t)b;
         len[idx] = (int32_t)(1 + (B - a));
         if (HYP) tS0l[idx] = (int32_t)S0l;
+    }
+    if (is_own) {
+        int32_t idx = s_base[1] + s_wcnt[1][wv] + __popcll(mo & ((1ull << lane) - 1ull));
+        o_tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
+        o_tb[idx] = (uint8_t)b;
+        o_rlen[idx] = (int32_t)Lmine;
+        o_ntl[idx] = (int32_t)((Lmine + LT - 1) / LT);
+        if (HYP) o_tS0l[idx] = (int32_t)S0l;
     }
 }
 
@@ -466,12 +492,13 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
 template <bool GE>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
-                                                int32_t thr, int lane, int32_t acc[4], int32_t sk[4])
+                                                int32_t thr, int lane, int32_t acc[4], int32_t sk[4], int head = 0)
 {
     const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
 #pragma unroll
     for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; sk[k] = e <= tl ? cpos[p_first - e] : INT32_MAX; acc[k] = 0; }
-    int32_t Q_hi = cpos[p_first + 1], Q_lo = cpos[p_first - tl];              // wave-uniform
+    // head != 0: step 0 is the candidate p_first itself (no column stepped over): the run ends in front of that column
+    int32_t Q_hi = cpos[p_first + 1 - head], Q_lo = cpos[p_first - tl];       // wave-uniform
     unsigned long long below = (1ull << lane) - 1ull;
     int32_t x = Q_lo & ~3;
     int4 c0 = make_int4(FILL, FILL, FILL, FILL), c1 = c0;
@@ -512,6 +539,124 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
             }
         }
         c0 = n0; c1 = n1;
+    }
+}
+
+// ------------------------------------------------------------------ long tasks with tiles of their own
+// A task with >= LT steps is cut into tiles counted from ITS OWN head (the last one partial): every tile lies in one task,
+// so all of them -- head and tail included -- take the uniform path: one contiguous run of the link array, suffix counts,
+// tile-local evaluation.  k_own_map: tile -> (task, tile index inside the task); k_lpass_own: one wave per tile;
+// k_fix_own: one wave per task merges its tiles (adding the counts made before each tile).
+__global__ void __launch_bounds__(256) k_own_map(const int64_t *__restrict__ toffs, int64_t ntask, int64_t ntile, const int4 *__restrict__ tdesc,
+                                                 const int32_t *__restrict__ rlen, int4 *__restrict__ rec, int32_t *__restrict__ tile_task)
+{
+    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntile) return;
+    int64_t lo = 0, hi = ntask;                       // last task with toffs[task] <= tile
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (toffs[mid] <= tile) lo = mid; else hi = mid;
+    }
+    int32_t kt = (int32_t)(tile - toffs[lo]);
+    int4 td = tdesc[lo];
+    int32_t rest = rlen[lo] - kt * LT;                // steps of the task from this tile on
+    int32_t tl = (rest < LT ? rest : LT) - 1;
+    rec[tile] = make_int4(td.x - kt * LT, td.z, td.w, (tl << 1) | (kt == 0 ? 1 : 0));      // {column of step 0, row, pos[row], tl | head}
+    tile_task[tile] = (int32_t)lo;
+}
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_lpass_own(int isA, int64_t ntile, const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_next,
+                                                   const int32_t *__restrict__ a_fpos, const int32_t *__restrict__ a_flast,
+                                                   int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2, const int4 *__restrict__ a_rec,
+                                                   const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ part)
+{
+    int lane = threadIdx.x & 63;
+    int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
+    int4 rec = a_rec[tile];
+    int head = rec.w & 1;
+    int32_t tl = rec.w >> 1;
+    int32_t acc[4], acc2[4] = {0, 0, 0, 0}, sk[4], sk2[4];
+    interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk, head);
+    if (HYP) interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc2, sk2, head);
+    int sel = tl >> 6;
+    if (lane == (tl & 63)) {
+        a_tileS[tile] = sel == 0 ? acc[0] : sel == 1 ? acc[1] : sel == 2 ? acc[2] : acc[3];
+        if (HYP) a_tileS2[tile] = sel == 0 ? acc2[0] : sel == 1 ? acc2[1] : sel == 2 ? acc2[2] : acc2[3];
+    }
+    // tile-local evaluation (the costs are affine in the counts; k_fix_own adds the counts made before the tile)
+    Best<TC, HYP> best; best_clear(best);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                       // increasing e = decreasing p: an earlier candidate wins ties
+        int32_t e = lane + 64 * k;
+        if (e <= tl && !(head && isA && e == 0)) {     // round A: the head element p = r is not a candidate
+            int32_t p = rec.x - e;
+            TC fv = dm_apply(M, alpha, (int64_t)(rec.y - p), (int64_t)(rec.z - sk[k]), (int64_t)acc[k], (int64_t)acc2[k]);
+            Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = p; c.nn = acc[k]; best_set_nl(c, acc2[k]);
+            best = better(best, c);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {                  // wave arg-min; ties -> larger p
+        int src = (lane + o) & 63;
+        Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
+        if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
+        bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
+        if (lane + o < 64 && take) best = c;
+    }
+    if (lane == 0) part[tile] = best;
+}
+
+template <typename TC, bool HYP, int WPT>
+__global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
+                                                 const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ tS0l,
+                                                 const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2, DevModel<TC> M,
+                                                 int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
+{
+    // WPT = 1: one wave per task (four tasks per block); WPT = 4: the whole block works on one task (rounds with a few
+    // tasks of thousands of tiles each)
+    __shared__ Best<TC, HYP> s_part[4];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t t = WPT == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x;
+    if (t >= ntask) return;                              // (block-uniform when WPT == 4)
+    int64_t k0 = toffs[t], k1 = toffs[t + 1];
+    int4 td = tdesc[t];
+    int64_t S0 = td.y, S0l = HYP ? (int64_t)tS0l[t] : 0;
+    Best<TC, HYP> acc; best_clear(acc);
+    for (int64_t k = k0 + (WPT == 1 ? lane : (int64_t)threadIdx.x); k < k1; k += 64 * WPT) {
+        Best<TC, HYP> c = part[k];
+        if (c.p >= 0) {
+            int64_t base = S0 + (tilePS[k] - tilePS[k0]);
+            int64_t base2 = HYP ? S0l + (tilePS2[k] - tilePS2[k0]) : 0;
+            c.v = cadd(c.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, base, base2));
+            c.nn = (int32_t)(c.nn + base);
+            if (HYP) best_set_nl(c, (int32_t)(best_nl(c) + base2));
+        }
+        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+        if (take) acc = c;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int src = (lane + o) & 63;
+        Best<TC, HYP> c; best_clear(c); c.v = shfl64(acc.v, src); c.p = __shfl(acc.p, src); c.nn = __shfl(acc.nn, src);
+        if (HYP) best_set_nl(c, __shfl(best_nl(acc), src));
+        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+        if (lane + o < 64 && take) acc = c;
+    }
+    if (WPT > 1) {
+        if (lane == 0) s_part[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int w = 1; w < 4; w++) {
+                Best<TC, HYP> c = s_part[w];
+                bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+                if (take) acc = c;
+            }
+    }
+    if (threadIdx.x == (WPT == 1 ? (unsigned)(wv * 64) : 0u)) {
+        int b = tb[t];
+        int64_t rw = (int64_t)b * n1 + PR((int64_t)td.z);
+        opt[rw] = acc.p; nnopt[rw] = acc.nn;
+        if (HYP) nlopt[rw] = best_nl(acc);
     }
 }
 
@@ -887,6 +1032,12 @@ struct LayerWork {
     DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
     DBuf<int32_t> open_list, fix_list, counts;          // tiles of long spans (k_span_short -> k_open / k_fix)
     DBuf<int4> tile_rec;                                // {first column, row, -, interior?} per tile (k_tile_t0)
+    // tasks with tiles of their own (k_lpass_own)
+    DBuf<int4> o_tdesc, o_rec;
+    DBuf<uint8_t> o_tb;
+    DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2;
+    DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
+    DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
 };
 
@@ -991,6 +1142,13 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         size_t mt = (size_t)Wk.max_tasks;
         Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
         if (hyp) Wk.tS0l.alloc(mt);
+        // a task with tiles of its own has >= LT candidates inside one rectangle: at most (rows x planes) / ... -- bounded by
+        // the number of row-tasks of the rounds whose rectangles are that wide; n/LT * planes is a safe cap
+        size_t mo = (size_t)(n / LT + 64) * (size_t)nbits + 1024;
+        if (mo > mt) mo = mt;
+        Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1);
+        if (hyp) Wk.o_tS0l.alloc(mo);
+
     }
     double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
     double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
@@ -1009,32 +1167,93 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
             if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
-        int32_t nlong = 0;
+        int32_t nlong = 0, nown = 0;
+        unsigned long long own_steps = 0;
+        const bool own_tiles = !(g_opt_dbg & 64);      // cp_set_option("dbg", 64): keep every long task in the flattened space
         {
             // per task: four gathers from the plane arrays + the record; short tasks also step over their columns here
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
-            if (!Wk.counts.p) Wk.counts.alloc(4);
-            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, sizeof(int32_t), s));
+            if (!Wk.counts.p) Wk.counts.alloc(8);        // [0] open tiles, [1] fix tiles, [2] flattened tasks, [3] own-tiled tasks, [4..5] their steps (64 bit)
+            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, 4 * sizeof(int32_t), s));
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, Wk.counts.p + 2,               \
-                (int32_t)g_opt_short_t, (int32_t)g_opt_short_e
+                (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
+                Wk.o_tS0l.p, Wk.counts.p + 3, reinterpret_cast<unsigned long long *>(Wk.counts.p + 4)
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
-            CP_HIP(hipMemcpyAsync(&nlong, Wk.counts.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            int32_t hc[4] = {0, 0, 0, 0};
+            CP_HIP(hipMemcpyAsync(hc, Wk.counts.p + 2, sizeof(hc), hipMemcpyDeviceToHost, s));
             CP_HIP(hipStreamSynchronize(s));
+            nlong = hc[0]; nown = hc[1];
+            memcpy(&own_steps, &hc[2], sizeof(own_steps));
         }
-        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d\n", R.isA, R.tau, (long long)R.ntask, nlong);
-        if (nlong <= 0) continue;
-        R.ntask = nlong;                            // from here on the round consists of the long tasks only
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d own=%d\n", R.isA, R.tau, (long long)R.ntask, nlong, nown);
+        if (nlong <= 0 && nown <= 0) continue;
         {
-            ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
-            exclusive_scan_i32(Wk.len.p, Wk.offs.p, R.ntask, Wk.scratch, s);
+            ProfScope ps(PROF_SCAN, s, 12.0 * (double)(nlong + nown));
+            if (nlong > 0) exclusive_scan_i32(Wk.len.p, Wk.offs.p, nlong, Wk.scratch, s);
+            if (nown > 0) exclusive_scan_i32(Wk.o_ntl.p, Wk.o_toffs.p, nown, Wk.scratch, s);
         }
-        int64_t T = 0;
-        CP_HIP(hipMemcpyAsync(&T, Wk.offs.p + R.ntask, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        int64_t T = 0, NT = 0;
+        if (nlong > 0) CP_HIP(hipMemcpyAsync(&T, Wk.offs.p + nlong, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        if (nown > 0) CP_HIP(hipMemcpyAsync(&NT, Wk.o_toffs.p + nown, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         CP_HIP(hipStreamSynchronize(s));
-        if (T <= 0) continue;
+        if (nown > 0 && NT > 0) {
+            // ---- long tasks with tiles of their own: map, stream + evaluate, merge
+            if (Wk.o_rec.n < (size_t)NT) {
+                Wk.o_rec.alloc((size_t)NT); Wk.o_task.alloc((size_t)NT); Wk.o_tileS.alloc((size_t)NT); Wk.o_tilePS.alloc((size_t)NT + 1);
+                Wk.o_part.alloc((size_t)NT);
+                if (hyp) { Wk.o_tileS2.alloc((size_t)NT); Wk.o_tilePS2.alloc((size_t)NT + 1); }
+            }
+            if (hyp && Wk.o_tileS2.n < (size_t)NT) { Wk.o_tileS2.alloc(Wk.o_tileS.n); Wk.o_tilePS2.alloc(Wk.o_tileS.n + 1); }
+            if (g_opt_dbg & 128) {                // poison what this block must write before it reads
+                int pat = (g_opt_dbg & 256) ? 0x00 : 0x7F;
+                CP_HIP(hipMemsetAsync(Wk.o_part.p, pat, Wk.o_part.bytes(), s));
+                CP_HIP(hipMemsetAsync(Wk.o_tileS.p, pat, sizeof(int32_t) * (size_t)NT, s));
+                CP_HIP(hipMemsetAsync(Wk.o_rec.p, pat, sizeof(int4) * (size_t)NT, s));
+                if (hyp) CP_HIP(hipMemsetAsync(Wk.o_tileS2.p, pat, sizeof(int32_t) * (size_t)NT, s));
+            }
+            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(NT, 256)), dim3(256), 0, s, Wk.o_toffs.p, (int64_t)nown, NT, Wk.o_tdesc.p, Wk.o_rlen.p,
+                               Wk.o_rec.p, Wk.o_task.p);
+            {
+                ProfScope ps(PROF_OWN, s, (double)own_steps * (4.0 * (avg_deg + self_deg) + 24.0));      // same bytes per step as dp_lpass
+#define LO_ARGS R.isA, NT, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr,            \
+                Wk.o_tileS.p, Wk.o_tileS2.p, Wk.o_rec.p, W, M, alpha
+                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true>), dim3((unsigned)cdiv(NT, 4)), dim3(256), 0, s, LO_ARGS, Wk.o_part.p);
+                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false>), dim3((unsigned)cdiv(NT, 4)), dim3(256), 0, s, LO_ARGS,
+                                            reinterpret_cast<Best<TC, false> *>(Wk.o_part.p));
+#undef LO_ARGS
+            }
+            {
+                ProfScope ps(PROF_CARRY, s, 12.0 * (double)NT);
+                exclusive_scan_i32(Wk.o_tileS.p, Wk.o_tilePS.p, NT, Wk.scratch, s);
+                if (hyp) exclusive_scan_i32(Wk.o_tileS2.p, Wk.o_tilePS2.p, NT, Wk.scratch, s);
+            }
+            {
+                ProfScope ps(PROF_FIX, s, 24.0 * (double)NT);
+                bool wide = NT > 64 * (int64_t)nown;             // on average more than 64 tiles per task: one block per task
+#define FO_ARGS (int64_t)nown, Wk.o_toffs.p
+#define FO_TAIL Wk.o_tdesc.p, Wk.o_tb.p
+                if (hyp) {
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3((unsigned)nown), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
+                                                 Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3((unsigned)cdiv((int64_t)nown, 4)), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
+                                            FO_TAIL, Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
+                } else {
+                    const Best<TC, false> *pp = reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p);
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3((unsigned)nown), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                                                 (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3((unsigned)cdiv((int64_t)nown, 4)), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                                            (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
+                }
+#undef FO_ARGS
+#undef FO_TAIL
+            }
+            CP_HIP(hipGetLastError());
+        }
+        if (nlong <= 0 || T <= 0) continue;
+        R.ntask = nlong;                            // from here on the round consists of the flattened tasks only
         if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld T=%lld\n", R.isA, R.tau, (long long)R.ntask, (long long)T);
         int64_t ntile = cdiv(T, LT);
         Wk.loc.ensure((size_t)T);

@@ -116,7 +116,7 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
         mm = mdl.marshal()
         for M_ in (A, B):
             rc2, p2, c2 = orc.dynamic_tables(M_, 5, 0, mm, None)
-            for dbg in (128, 128 + 256, 0):
+            for dbg in (128, 128 + 256, 64, 64 + 128, 0):       # 64: long tasks stay in the flattened space (no tiles of their own)
                 hip.set_option("dbg", dbg)
                 try:
                     rc1, p1, c1 = hip.dynamic_tables(M_, 5, 0, mm, None)
