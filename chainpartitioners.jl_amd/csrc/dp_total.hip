@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int32_t *__restrict__ tS0l, int32_t *__restrict__ nlong, int32_t SHORT_T, int32_t SHORT_E,
                                                       int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
-                                                      unsigned long long *__restrict__ own_steps)
+                                                      unsigned long long *__restrict__ own_steps, int32_t OWN_MIN)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                 }
                 opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
             }
-        } else if (o_tdesc && L >= LT) {
+        } else if (o_tdesc && L >= OWN_MIN) {
             is_own = true;                           // long enough for tiles of its own (k_lpass_own): every tile is uniform
         } else {
             is_long = true;
@@ -1144,7 +1144,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (hyp) Wk.tS0l.alloc(mt);
         // a task with tiles of its own has >= LT candidates inside one rectangle: at most (rows x planes) / ... -- bounded by
         // the number of row-tasks of the rounds whose rectangles are that wide; n/LT * planes is a safe cap
-        size_t mo = (size_t)(n / LT + 64) * (size_t)nbits + 1024;
+        size_t mo = (size_t)(n / 32 + 64) * (size_t)nbits + 1024;      // (own_min >= 64: at most n / 64 such tasks per plane and round)
         if (mo > mt) mo = mt;
         Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1);
         if (hyp) Wk.o_tS0l.alloc(mo);
@@ -1178,7 +1178,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, Wk.counts.p + 2,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
-                Wk.o_tS0l.p, Wk.counts.p + 3, reinterpret_cast<unsigned long long *>(Wk.counts.p + 4)
+                Wk.o_tS0l.p, Wk.counts.p + 3, reinterpret_cast<unsigned long long *>(Wk.counts.p + 4), (int32_t)g_opt_own_min
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS

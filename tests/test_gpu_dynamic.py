@@ -123,13 +123,13 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
                 finally:
                     hip.set_option("dbg", 0)
                 assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), (dbg, M_)
-            for (st, se) in ((0, 0), (1, 64), (100, 100000)):
-                hip.set_option("short_t", st); hip.set_option("short_e", se)
+            for (st, se, om) in ((0, 0, 64), (1, 64, 256), (100, 100000, 1000), (4, 64, 100)):
+                hip.set_option("short_t", st); hip.set_option("short_e", se); hip.set_option("own_min", om)
                 try:
                     rc1, p1, c1 = hip.dynamic_tables(M_, 5, 0, mm, None)
                 finally:
-                    hip.set_option("short_t", 4); hip.set_option("short_e", 64)
-                assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, M_)
+                    hip.set_option("short_t", 4); hip.set_option("short_e", 64); hip.set_option("own_min", 64)
+                assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, om, M_)
 
 
 def test_plain_c_client_runs(hip):
