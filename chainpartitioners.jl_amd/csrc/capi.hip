@@ -440,6 +440,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "dbg")) { g_opt_dbg = value; return CP_OK; }
     if (!strcmp(name, "short_t")) { g_opt_short_t = value; return CP_OK; }
     if (!strcmp(name, "short_e")) { g_opt_short_e = value; return CP_OK; }
+    if (!strcmp(name, "rpass_ch")) { int64_t v = 16; while (v < value && v < 4096) v <<= 1; g_opt_rpass_ch = v; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     set_error("unknown option");
     return CP_EINVAL;

@@ -90,6 +90,8 @@ void prof_collect();   // resolve pending event pairs (after a stream sync)
 // ------------------------------------------------------------------ device-wide exclusive scan (int32 -> int64)
 // out has n+1 entries: out[i] = sum_{t<i} in[t], out[n] = total.
 void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s);
+void exclusive_scan_i32_devn(const int32_t *in, int64_t *out, const int32_t *n_dev, int64_t n_max, int64_t *total_out,
+                             DBuf<int64_t> &scratch, hipStream_t s);
 void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s);
 
 // wave64 helpers

@@ -39,9 +39,13 @@ constexpr int SCAN_T = 256;
 constexpr int SCAN_I = 8;
 constexpr int SCAN_TILE = SCAN_T * SCAN_I;
 
-__global__ void __launch_bounds__(SCAN_T) k_scan_reduce(const int32_t *__restrict__ in, int64_t *__restrict__ bsum, int64_t n)
+// n_dev != nullptr: the element count lives on the device (written by an earlier kernel of the stream); the grid is sized
+// for an upper bound and blocks beyond the count contribute zeros
+__global__ void __launch_bounds__(SCAN_T) k_scan_reduce(const int32_t *__restrict__ in, int64_t *__restrict__ bsum, int64_t n,
+                                                        const int32_t *__restrict__ n_dev)
 {
     __shared__ int64_t sh[SCAN_T / 64];
+    if (n_dev) n = *n_dev;
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
     int64_t s = 0;
 #pragma unroll
@@ -79,9 +83,11 @@ __global__ void __launch_bounds__(1024) k_scan_blocksums(int64_t *__restrict__ b
 
 template <typename OutT>
 __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict__ in, OutT *__restrict__ out,
-                                                       const int64_t *__restrict__ bsum, int64_t n, int64_t nb)
+                                                       const int64_t *__restrict__ bsum, int64_t n, int64_t nb,
+                                                       const int32_t *__restrict__ n_dev, int64_t *__restrict__ total_out)
 {
     __shared__ int64_t sh[SCAN_T];
+    if (n_dev) n = *n_dev;
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
     int32_t v[SCAN_I];
     int64_t s = 0;
@@ -98,7 +104,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const int32_t *__restrict
     int64_t run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
 #pragma unroll
     for (int k = 0; k < SCAN_I; k++) if (base + k < n) { out[base + k] = (OutT)run; run += v[k]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (OutT)bsum[nb];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[n] = (OutT)bsum[nb]; if (total_out) *total_out = bsum[nb]; }
 }
 
 void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s)
@@ -106,9 +112,24 @@ void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t
     if (n <= 0) { CP_HIP(hipMemsetAsync(out, 0, sizeof(int64_t), s)); return; }
     int64_t nb = cdiv(n, SCAN_TILE);
     scratch.ensure((size_t)nb + 1);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n, (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int64_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int64_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb,
+                       (const int32_t *)nullptr, (int64_t *)nullptr);
+    CP_HIP(hipGetLastError());
+}
+
+// same with the element count on the device (n_dev <= n_max); the total also goes to *total_out (device)
+void exclusive_scan_i32_devn(const int32_t *in, int64_t *out, const int32_t *n_dev, int64_t n_max, int64_t *total_out,
+                             DBuf<int64_t> &scratch, hipStream_t s)
+{
+    if (n_max <= 0) n_max = 1;
+    int64_t nb = cdiv(n_max, SCAN_TILE);
+    scratch.ensure((size_t)nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, (int64_t)0, n_dev);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int64_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, (int64_t)0, nb,
+                       n_dev, total_out);
     CP_HIP(hipGetLastError());
 }
 
@@ -117,9 +138,10 @@ void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int
     if (n <= 0) { CP_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), s)); return; }
     int64_t nb = cdiv(n, SCAN_TILE);
     scratch.ensure((size_t)nb + 1);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, scratch.p, n, (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, s, scratch.p, nb);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int32_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<int32_t>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, scratch.p, n, nb,
+                       (const int32_t *)nullptr, (int64_t *)nullptr);
     CP_HIP(hipGetLastError());
 }
 

@@ -19,6 +19,7 @@ namespace cpk {
 int64_t g_opt_force_brute = 0;
 int64_t g_opt_short_t = 4, g_opt_short_e = 64;
 int64_t g_opt_own_min = 64;
+int64_t g_opt_rpass_ch = 512;
 int64_t g_opt_brute_max_n = 200000;
 int64_t g_opt_dbg = 0;
 

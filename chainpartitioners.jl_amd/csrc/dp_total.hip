@@ -1111,7 +1111,7 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
         if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
     } else {
-        int ch_cols = 256;
+        int ch_cols = (int)g_opt_rpass_ch;          // columns per wave (cp_set_option("rpass_ch"))
         int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
         if (cpr == 1) ch_cols = 1 << tau;
         int64_t waves = nrows * cpr;
@@ -1160,7 +1160,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
-            if (((int64_t)1 << R.tau) > 256)          // several chunks per row accumulate with atomics: clear first
+            if (((int64_t)1 << R.tau) > g_opt_rpass_ch)   // several chunks per row accumulate with atomics: clear first
                 hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
                                    Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
                                    (int32_t *)nullptr);
@@ -1173,8 +1173,9 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         {
             // per task: four gathers from the plane arrays + the record; short tasks also step over their columns here
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
-            if (!Wk.counts.p) Wk.counts.alloc(8);        // [0] open tiles, [1] fix tiles, [2] flattened tasks, [3] own-tiled tasks, [4..5] their steps (64 bit)
-            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, 4 * sizeof(int32_t), s));
+            if (!Wk.counts.p) Wk.counts.alloc(12);       // [0] open tiles, [1] fix tiles, [2] flattened tasks, [3] own-tiled tasks,
+                                                         // 64-bit: [4..5] their steps, [6..7] flattened steps T, [8..9] own tiles NT
+            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, 8 * sizeof(int32_t), s));
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, Wk.counts.p + 2,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
@@ -1182,23 +1183,27 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
-            int32_t hc[4] = {0, 0, 0, 0};
+        }
+        int64_t T = 0, NT = 0;
+        {
+            // both scans read their element count on the device: ONE host sync per round brings back every count and total
+            ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
+            exclusive_scan_i32_devn(Wk.len.p, Wk.offs.p, Wk.counts.p + 2, R.ntask, reinterpret_cast<int64_t *>(Wk.counts.p + 6), Wk.scratch, s);
+            if (own_tiles)
+                exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, Wk.counts.p + 3, std::min<int64_t>(R.ntask, (int64_t)Wk.o_ntl.n),
+                                        reinterpret_cast<int64_t *>(Wk.counts.p + 8), Wk.scratch, s);
+        }
+        {
+            int32_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             CP_HIP(hipMemcpyAsync(hc, Wk.counts.p + 2, sizeof(hc), hipMemcpyDeviceToHost, s));
             CP_HIP(hipStreamSynchronize(s));
             nlong = hc[0]; nown = hc[1];
             memcpy(&own_steps, &hc[2], sizeof(own_steps));
+            memcpy(&T, &hc[4], sizeof(T));
+            memcpy(&NT, &hc[6], sizeof(NT));
         }
-        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d own=%d\n", R.isA, R.tau, (long long)R.ntask, nlong, nown);
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d own=%d T=%lld NT=%lld\n", R.isA, R.tau, (long long)R.ntask, nlong, nown, (long long)T, (long long)NT);
         if (nlong <= 0 && nown <= 0) continue;
-        {
-            ProfScope ps(PROF_SCAN, s, 12.0 * (double)(nlong + nown));
-            if (nlong > 0) exclusive_scan_i32(Wk.len.p, Wk.offs.p, nlong, Wk.scratch, s);
-            if (nown > 0) exclusive_scan_i32(Wk.o_ntl.p, Wk.o_toffs.p, nown, Wk.scratch, s);
-        }
-        int64_t T = 0, NT = 0;
-        if (nlong > 0) CP_HIP(hipMemcpyAsync(&T, Wk.offs.p + nlong, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        if (nown > 0) CP_HIP(hipMemcpyAsync(&NT, Wk.o_toffs.p + nown, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        CP_HIP(hipStreamSynchronize(s));
         if (nown > 0 && NT > 0) {
             // ---- long tasks with tiles of their own: map, stream + evaluate, merge
             if (Wk.o_rec.n < (size_t)NT) {
