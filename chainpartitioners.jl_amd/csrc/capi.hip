@@ -176,7 +176,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     for (int64_t k = 2; k <= K; k++) {
         int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
         bool last = (k == K);
-        if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work, 0, n);
+        if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work, last ? n : 0, n);   // layer K: row n+1 only (:34)
         else dp_brute_layer<TC>(A, HM.d, alpha_of(k), combine, prevc, curc, pk, last ? n : 0, n);   // layer K: row n+1 only (:34)
         dump_layer(k, curc, last);
         std::swap(prevc, curc);
@@ -441,6 +441,8 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "short_t")) { g_opt_short_t = value; return CP_OK; }
     if (!strcmp(name, "short_e")) { g_opt_short_e = value; return CP_OK; }
     if (!strcmp(name, "rpass_ch")) { int64_t v = 16; while (v < value && v < 4096) v <<= 1; g_opt_rpass_ch = v; return CP_OK; }
+    if (!strcmp(name, "prof_only")) { g_prof_only = (int)value; return CP_OK; }
+    if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     set_error("unknown option");
     return CP_EINVAL;

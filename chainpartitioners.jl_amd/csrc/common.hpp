@@ -64,6 +64,8 @@ enum { PROF_EXPAND = 0, PROF_EVAL, PROF_SETUP, PROF_SCAN, PROF_CARRY, PROF_FIX, 
        PROF_BRUTE, PROF_WAVELET, PROF_QUERY, PROF_BISECT, PROF_CHUNK, PROF_RPASS, PROF_OWN, PROF_NSLOTS };
 extern ProfSlot g_prof[PROF_NSLOTS];
 extern bool g_prof_on;
+extern int g_prof_only;              // >= 0: only this slot records events (cp_set_option("prof_only")): 2 events per round instead of ~40
+inline bool prof_active(int slot) { return g_prof_on && (g_prof_only < 0 || g_prof_only == slot); }
 
 struct ProfPending { int slot; hipEvent_t a, b; double bytes; };
 extern std::vector<ProfPending> g_prof_pending;
@@ -77,7 +79,7 @@ inline hipEvent_t prof_event() {
 // RAII scope: records an event pair around the launches issued inside it
 struct ProfScope {
     int slot; hipStream_t s; hipEvent_t a{}, b{}; double bytes; bool on;
-    ProfScope(int slot_, hipStream_t s_, double alg_bytes) : slot(slot_), s(s_), bytes(alg_bytes), on(g_prof_on) {
+    ProfScope(int slot_, hipStream_t s_, double alg_bytes) : slot(slot_), s(s_), bytes(alg_bytes), on(prof_active(slot_)) {
         if (on) { a = prof_event(); b = prof_event(); CP_HIP(hipEventRecord(a, s)); }
     }
     ~ProfScope() {

@@ -16,6 +16,7 @@ ProfSlot g_prof[PROF_NSLOTS] = {
     {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
     {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}};
 bool g_prof_on = false;
+int g_prof_only = -1;
 std::vector<ProfPending> g_prof_pending;
 std::vector<hipEvent_t> g_event_pool;
 

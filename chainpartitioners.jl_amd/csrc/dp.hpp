@@ -38,6 +38,8 @@ int32_t run_plaid_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order
 template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
+extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
+extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
 extern int64_t g_opt_rpass_ch;                 // columns per wave in k_rpass_wave (power of two >= 16)
 extern int64_t g_opt_own_min;                  // tasks with at least this many steps get tiles of their own (>= 64)
 extern int64_t g_opt_short_t, g_opt_short_e;   // k_setup_short: tasks with <= short_t candidates and <= short_e link entries finish in setup

@@ -56,6 +56,16 @@ struct RoundDesc {
     int64_t extra[64];
 };
 
+// Per-round counters, on the device (one record per round, kept for the whole layer).  Kernels read their loop bounds from
+// here, so the host can enqueue a whole layer without waiting for a count to come back (dp_total_layer).
+struct RoundCounts {
+    int32_t n_open, n_fix;            // work lists of k_span_short (tiles of long spans)
+    int32_t nlong, nown;              // flattened tasks / tasks with tiles of their own (k_setup_short)
+    unsigned long long own_steps;     // steps of the latter
+    int64_t T, NT;                    // flattened steps / own tiles (scan totals)
+    int32_t ntile, err;               // cdiv(T, LT); 1: a buffer sized from the prediction is too small (the layer is redone)
+};
+
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
 {
     if (R.isA) { r = t < R.a_nmain ? R.a_r0 + t : R.extra[t - R.a_nmain]; b = __ffsll((long long)r) - 1; return; }
@@ -282,7 +292,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int32_t *__restrict__ tS0l, int32_t *__restrict__ nlong, int32_t SHORT_T, int32_t SHORT_E,
                                                       int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
-                                                      unsigned long long *__restrict__ own_steps, int32_t OWN_MIN)
+                                                      unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
+                                                      int32_t *__restrict__ err)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -367,6 +378,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     }
     if (is_own) {
         int32_t idx = s_base[1] + s_wcnt[1][wv] + __popcll(mo & ((1ull << lane) - 1ull));
+        if (idx >= o_cap) { *err = 1; return; }          // cannot happen (LayerWork sizes the list for the worst case); never write outside
         o_tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
         o_tb[idx] = (uint8_t)b;
         o_rlen[idx] = (int32_t)Lmine;
@@ -377,11 +389,13 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
 
 // ------------------------------------------------------------------ tile task table (one wave = one tile)
 // first task overlapping each tile: last t with offs[t] <= tile*LT (one thread per tile; offs[0] = 0)
-__global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ offs, int64_t ntask, int64_t ntile, int64_t T,
-                                                 const int4 *__restrict__ tdesc, int64_t *__restrict__ tile_t0, int4 *__restrict__ tile_rec, int no_interior)
+__global__ void __launch_bounds__(256) k_tile_t0(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ offs,
+                                                 const int4 *__restrict__ tdesc, int64_t *__restrict__ tile_t0, int4 *__restrict__ tile_rec, int no_interior,
+                                                 int64_t *__restrict__ taskR)
 {
-    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= ntile) return;
+    const int64_t ntask = rc->nlong, ntile = rc->ntile, T = rc->T;
+    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tile < ntile; tile += (int64_t)gridDim.x * blockDim.x) {
+    taskR[tile] = -1;                                  // "no task continues beyond this tile" until k_lpass says otherwise
     int64_t tile_start = tile * LT;
     int64_t lo = 0, hi = ntask;
     while (hi - lo > 1) {
@@ -397,6 +411,7 @@ __global__ void __launch_bounds__(256) k_tile_t0(const int64_t *__restrict__ off
         rec = make_int4(td.x - (int32_t)(tile_start - toff), td.z, td.w, 1);
     }
     tile_rec[tile] = rec;
+    }
 }
 
 // loads the offsets (relative to the tile start, 32-bit) of the tasks overlapping the tile and a bitmap of the
@@ -547,11 +562,11 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
 // so all of them -- head and tail included -- take the uniform path: one contiguous run of the link array, suffix counts,
 // tile-local evaluation.  k_own_map: tile -> (task, tile index inside the task); k_lpass_own: one wave per tile;
 // k_fix_own: one wave per task merges its tiles (adding the counts made before each tile).
-__global__ void __launch_bounds__(256) k_own_map(const int64_t *__restrict__ toffs, int64_t ntask, int64_t ntile, const int4 *__restrict__ tdesc,
+__global__ void __launch_bounds__(256) k_own_map(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ toffs, const int4 *__restrict__ tdesc,
                                                  const int32_t *__restrict__ rlen, int4 *__restrict__ rec, int32_t *__restrict__ tile_task)
 {
-    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= ntile) return;
+    const int64_t ntask = rc->nown, ntile = rc->NT;
+    for (int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tile < ntile; tile += (int64_t)gridDim.x * blockDim.x) {
     int64_t lo = 0, hi = ntask;                       // last task with toffs[task] <= tile
     while (hi - lo > 1) {
         int64_t mid = (lo + hi) >> 1;
@@ -563,17 +578,22 @@ __global__ void __launch_bounds__(256) k_own_map(const int64_t *__restrict__ tof
     int32_t tl = (rest < LT ? rest : LT) - 1;
     rec[tile] = make_int4(td.x - kt * LT, td.z, td.w, (tl << 1) | (kt == 0 ? 1 : 0));      // {column of step 0, row, pos[row], tl | head}
     tile_task[tile] = (int32_t)lo;
+    }
 }
 
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_lpass_own(int isA, int64_t ntile, const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_next,
+__global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *__restrict__ rc, const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_next,
                                                    const int32_t *__restrict__ a_fpos, const int32_t *__restrict__ a_flast,
                                                    int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2, const int4 *__restrict__ a_rec,
                                                    const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ part)
 {
+    // (Tried: tiles visited in column order, one contiguous share of the order per XCD, so that the ~10 passes of the bit planes
+    //  over a column meet in L2: 10 % off this kernel, less than the sort of the tile list costs.)
+    // (No grid-stride loop here: it costs 14 VGPRs = two waves per SIMD.  The host launches one wave per tile of the buffer's
+    //  CAPACITY, which k_round_finish has checked the true count against.)
     int lane = threadIdx.x & 63;
     int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntile) return;
+    if (tile >= rc->NT) return;
     int4 rec = a_rec[tile];
     int head = rec.w & 1;
     int32_t tl = rec.w >> 1;
@@ -608,7 +628,7 @@ __global__ void __launch_bounds__(256) k_lpass_own(int isA, int64_t ntile, const
 }
 
 template <typename TC, bool HYP, int WPT>
-__global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
+__global__ void __launch_bounds__(256) k_fix_own(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
                                                  const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ tS0l,
                                                  const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2, DevModel<TC> M,
                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
@@ -617,8 +637,9 @@ __global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *_
     // tasks of thousands of tiles each)
     __shared__ Best<TC, HYP> s_part[4];
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int64_t t = WPT == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x;
-    if (t >= ntask) return;                              // (block-uniform when WPT == 4)
+    const int64_t ntask = rc->nown;
+    // (the loop is block-uniform when WPT == 4: the barrier below is reached by the whole block)
+    for (int64_t t = WPT == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x; t < ntask; t += WPT == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x) {
     int64_t k0 = toffs[t], k1 = toffs[t + 1];
     int4 td = tdesc[t];
     int64_t S0 = td.y, S0l = HYP ? (int64_t)tS0l[t] : 0;
@@ -643,6 +664,7 @@ __global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *_
         if (lane + o < 64 && take) acc = c;
     }
     if (WPT > 1) {
+        __syncthreads();                                 // (the previous task's partials have been read)
         if (lane == 0) s_part[wv] = acc;
         __syncthreads();
         if (threadIdx.x == 0)
@@ -658,6 +680,7 @@ __global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *_
         opt[rw] = acc.p; nnopt[rw] = acc.nn;
         if (HYP) nlopt[rw] = best_nl(acc);
     }
+    }
 }
 
 // ------------------------------------------------------------------ left part: stream, scan, evaluate, arg-min
@@ -665,7 +688,7 @@ __global__ void __launch_bounds__(256) k_fix_own(int64_t ntask, const int64_t *_
 // a column p joining on the left adds the rows with first == p and last < r.
 
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const int64_t *__restrict__ a_offs,
+__global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, const RoundCounts *__restrict__ rc, const int64_t *__restrict__ a_offs,
                                                   const int4 *__restrict__ a_tdesc, const int32_t *__restrict__ a_tS0l,
                                                   const uint8_t *__restrict__ a_tb, const int32_t *__restrict__ a_pos,
                                                   const int32_t *__restrict__ a_next, const int32_t *__restrict__ a_fpos,
@@ -681,6 +704,8 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     __shared__ int32_t s_off_all[4][LT + 2];
     __shared__ unsigned long long s_hd_all[4][LT / 64];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (no grid-stride loop: the host launches one wave per tile of the buffers' capacity, see k_lpass_own)
+    const int64_t T = rc->T, ntask = rc->nlong;
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     int64_t tile_start = tile * LT;
     bool active = tile_start < T;
@@ -694,7 +719,7 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
     int64_t t0 = 0; int cnt = 0;
     if (!interior) {
         t0 = active ? a_tile_t0[tile] : 0;
-        load_tile_tasks(a_offs, R.ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
+        load_tile_tasks(a_offs, ntask, t0, tile_start, active, s_off, s_hd, lane, cnt);
     }
     __syncthreads();
     if (!active) return;
@@ -826,7 +851,7 @@ __global__ void __launch_bounds__(256, 6) k_lpass(RoundDesc R, int64_t T, const 
 constexpr int SPAN_SHORT = 32;
 
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
+__global__ void __launch_bounds__(256) k_span_short(RoundDesc R, RoundCounts *__restrict__ rc, const int64_t *__restrict__ a_offs,
                                                     const int4 *__restrict__ a_tdesc, const int32_t *__restrict__ a_tS0l,
                                                     const uint8_t *__restrict__ a_tb, const int32_t *__restrict__ a_pos,
                                                     const int32_t *__restrict__ a_loc, const int32_t *__restrict__ a_loc2,
@@ -834,11 +859,13 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
                                                     const int32_t *__restrict__ a_tileS, const int32_t *__restrict__ a_tileS2,
                                                     const Best<TC, HYP> *__restrict__ partR, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                     int32_t *__restrict__ a_opt, int32_t *__restrict__ a_nnopt, int32_t *__restrict__ a_nlopt,
-                                                    int32_t *__restrict__ open_list, int32_t *__restrict__ fix_list, int32_t *__restrict__ counts,
+                                                    int32_t *__restrict__ open_list, int32_t *__restrict__ fix_list,
                                                     const int4 *__restrict__ a_tile_rec)
 {
-    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
+    const int64_t ntile = rc->ntile;
+    for (int64_t tbase = (int64_t)blockIdx.x * blockDim.x; tbase < ntile; tbase += (int64_t)gridDim.x * blockDim.x) {      // wave-uniform
+    int64_t tile = tbase + threadIdx.x;
     bool in = tile < ntile;
     int64_t n1 = R.n + 1;
     // ---- role 1: this tile is the head tile of a task that continues beyond it
@@ -888,29 +915,30 @@ __global__ void __launch_bounds__(256) k_span_short(RoundDesc R, int64_t T, int6
     unsigned long long mo = __ballot(open_long), mf = __ballot(fix_long);
     int32_t bo = 0, bf = 0;
     if (lane == 0) {
-        if (mo) bo = atomicAdd(&counts[0], (int32_t)__popcll(mo));
-        if (mf) bf = atomicAdd(&counts[1], (int32_t)__popcll(mf));
+        if (mo) bo = atomicAdd(&rc->n_open, (int32_t)__popcll(mo));
+        if (mf) bf = atomicAdd(&rc->n_fix, (int32_t)__popcll(mf));
     }
     bo = __shfl(bo, 0); bf = __shfl(bf, 0);
     unsigned long long below = (1ull << lane) - 1ull;
     if (open_long) open_list[bo + __popcll(mo & below)] = (int32_t)tile;
     if (fix_long) fix_list[bf + __popcll(mf & below)] = (int32_t)tile;
+    }
 }
 
 // open-left part of a tile of a long span (the task started in an earlier tile): one wave per listed tile
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t ntile, const int64_t *__restrict__ a_offs,
+__global__ void __launch_bounds__(256) k_open(RoundDesc R, const RoundCounts *__restrict__ rc, const int64_t *__restrict__ a_offs,
                                               const int4 *__restrict__ a_tdesc,
                                               const int32_t *__restrict__ a_tS0l,
                                               const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_loc,
                                               const int32_t *__restrict__ a_loc2, const int64_t *__restrict__ a_tile_t0,
                                               const int64_t *__restrict__ tilePS,
                                               const int64_t *__restrict__ tilePS2, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                              Best<TC, HYP> *__restrict__ partL, const int32_t *__restrict__ open_list, const int32_t *__restrict__ counts)
+                                              Best<TC, HYP> *__restrict__ partL, const int32_t *__restrict__ open_list)
 {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t nw = (int64_t)gridDim.x * 4;
-    int64_t cnt = counts[0];
+    const int64_t cnt = rc->n_open, T = rc->T;
     for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < cnt; w += nw) {
         int64_t tile = open_list[w];
         int64_t tile_start = tile * LT;
@@ -949,17 +977,17 @@ __global__ void __launch_bounds__(256) k_open(RoundDesc R, int64_t T, int64_t nt
 // a task of a long span: combine the head tile's partial with the partials of the tiles it covers
 // (one wave per listed head tile)
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_fix(int64_t ntile, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
+__global__ void __launch_bounds__(256) k_fix(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ offs, const int64_t *__restrict__ taskR,
                                              const Best<TC, HYP> *__restrict__ partL, const Best<TC, HYP> *__restrict__ partR,
                                              const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
                                              int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
-                                             const int32_t *__restrict__ fix_list, const int32_t *__restrict__ counts,
+                                             const int32_t *__restrict__ fix_list,
                                              const int4 *__restrict__ tile_rec, const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2,
                                              const int32_t *__restrict__ tS0l, DevModel<TC> M)
 {
     int lane = threadIdx.x & 63;
     int64_t nw = (int64_t)gridDim.x * 4;
-    int64_t cnt = counts[1];
+    const int64_t cnt = rc->n_fix;
     for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < cnt; w += nw) {
         int64_t tile = fix_list[w];
         int64_t t = taskR[tile];
@@ -1020,6 +1048,15 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t
     ptr[r] = (int32_t)bp;
 }
 
+// ------------------------------------------------------------------ end of a round's counting phase
+// One thread: derives the tile count and checks the scan totals against the capacities of the buffers the host sized from
+// its prediction (the previous layer); on overflow the round's work is dropped and the flag makes the host redo the layer.
+__global__ void k_round_finish(RoundCounts *__restrict__ rc, int64_t capT, int64_t capNT)
+{
+    if (rc->T > capT || rc->NT > capNT || rc->err) { rc->err = 1; rc->T = 0; rc->NT = 0; rc->nlong = 0; rc->nown = 0; }
+    rc->ntile = (int32_t)((rc->T + LT - 1) / LT);
+}
+
 // ------------------------------------------------------------------ host driver for one layer
 template <typename TC>
 struct LayerWork {
@@ -1030,7 +1067,7 @@ struct LayerWork {
     DBuf<uint8_t> tb;
     DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
     DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
-    DBuf<int32_t> open_list, fix_list, counts;          // tiles of long spans (k_span_short -> k_open / k_fix)
+    DBuf<int32_t> open_list, fix_list;                  // tiles of long spans (k_span_short -> k_open / k_fix)
     DBuf<int4> tile_rec;                                // {first column, row, -, interior?} per tile (k_tile_t0)
     // tasks with tiles of their own (k_lpass_own)
     DBuf<int4> o_tdesc, o_rec;
@@ -1039,6 +1076,24 @@ struct LayerWork {
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
+    DBuf<RoundCounts> rc;                               // per-round counters of the current layer (device)
+    std::vector<RoundCounts> pred;                      // ... of the previous layer (host): sizes the next one
+    bool pred_ok = false; int64_t pred_rlo = 0, pred_rhi = 0;
+    void ensure_own(size_t NT) {                        // per-tile arrays of the own-tiled tasks
+        if (o_rec.n >= NT && o_rec.n > 0) return;
+        size_t c = NT > 0 ? NT : 1;
+        o_rec.alloc(c); o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c);
+        if (hyp) { o_tileS2.alloc(c); o_tilePS2.alloc(c + 1); }
+    }
+    void ensure_flat(size_t T) {                        // per-step and per-tile arrays of the flattened tasks
+        if (loc.n >= T && loc.n > 0) return;
+        size_t c = T > 0 ? T : 1, nt = (c + LT - 1) / LT;
+        loc.alloc(c);
+        if (hyp) loc2.alloc(c);
+        tileS.alloc(nt); tilePS.alloc(nt + 1); tile_t0.alloc(nt); partL.alloc(nt); partR.alloc(nt); taskR.alloc(nt);
+        open_list.alloc(nt); fix_list.alloc(nt); tile_rec.alloc(nt);
+        if (hyp) { tileS2.alloc(nt); tilePS2.alloc(nt + 1); }
+    }
 };
 
 // number of rows r <= x of the form (base << (b+1)) | (1 << b) | ((2v+1) << tau): the rows with ctz == tau whose bit b is set
@@ -1120,43 +1175,38 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     }
 }
 
+// Runs the rounds of one layer.  `spec`: the per-round counts of the PREVIOUS layer (Wk.pred) size the grids, the buffers and
+// decide which stages are launched; every kernel reads its true loop bounds from the device (RoundCounts) and walks them with
+// grid strides, so a wrong prediction costs time, never correctness -- except a stage skipped or a buffer too small, which
+// run_layer reports (false) after the layer and the caller redoes the layer with spec = false: one host sync per round brings
+// the exact counts back before the dependent launches (the only mode of the first layer).
 template <typename TC>
-void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_,
-                    int64_t rlo, int64_t rhi)
+static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, LayerWork<TC> &Wk,
+                      int64_t rlo, int64_t rhi, bool spec)
 {
-    auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
     hipStream_t s = A->stream;
-    int64_t n = A->n;
-    bool hyp = M.kind == CP_MODEL_HYPEREDGE_CUT;
-    int nbits = 1;
-    while (((int64_t)1 << nbits) <= n) nbits++;
-    CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
-    if (Wk.n != n || Wk.hyp != hyp) {
-        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp;
-        size_t plane = (size_t)nbits * (size_t)(n + 1);
-        Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
-        if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
-        int64_t mx = n;
-        for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n, 0, n); if (R.ntask > mx) mx = R.ntask; }
-        Wk.max_tasks = mx > 0 ? mx : 1;
-        size_t mt = (size_t)Wk.max_tasks;
-        Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
-        if (hyp) Wk.tS0l.alloc(mt);
-        // a task with tiles of its own has >= LT candidates inside one rectangle: at most (rows x planes) / ... -- bounded by
-        // the number of row-tasks of the rounds whose rectangles are that wide; n/LT * planes is a safe cap
-        size_t mo = (size_t)(n / 32 + 64) * (size_t)nbits + 1024;      // (own_min >= 64: at most n / 64 such tasks per plane and round)
-        if (mo > mt) mo = mt;
-        Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1);
-        if (hyp) Wk.o_tS0l.alloc(mo);
+    const int64_t n = A->n;
+    const bool hyp = Wk.hyp;
+    const int nbits = Wk.nbits;
+    const double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
+    const double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
+    const double step_bytes = 4.0 * (avg_deg + self_deg) + 24.0;
+    const bool own_tiles = !(g_opt_dbg & 64);      // cp_set_option("dbg", 64): keep every long task in the flattened space
+    const int NR = nbits + 1;
+    CP_HIP(hipMemsetAsync(Wk.rc.p, 0, sizeof(RoundCounts) * (size_t)NR, s));
+    std::vector<RoundCounts> used((size_t)NR);          // what the host sized each round with
+    memset(used.data(), 0, sizeof(RoundCounts) * (size_t)NR);
+    struct Patch { size_t idx; int rd; int kind; };
+    std::vector<Patch> patches;                          // profile records whose algorithmic bytes depend on the true counts
+    auto note = [&](int rd, int kind) { if (prof_active(kind == 0 ? PROF_OWN : PROF_EXPAND)) patches.push_back({g_prof_pending.size() - 1, rd, kind}); };
+    auto grow = [](int64_t v) { return v + (v >> 2) + 1024; };     // head room over the prediction
 
-    }
-    double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
-    double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi);
         else make_round(R, false, nbits - rd, nbits, n, rlo, rhi);
         if (R.ntask <= 0) continue;
+        RoundCounts *rc = Wk.rc.p + rd;
         if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
@@ -1167,89 +1217,83 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
             if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
-        int32_t nlong = 0, nown = 0;
-        unsigned long long own_steps = 0;
-        const bool own_tiles = !(g_opt_dbg & 64);      // cp_set_option("dbg", 64): keep every long task in the flattened space
         {
             // per task: four gathers from the plane arrays + the record; short tasks also step over their columns here
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
-            if (!Wk.counts.p) Wk.counts.alloc(12);       // [0] open tiles, [1] fix tiles, [2] flattened tasks, [3] own-tiled tasks,
-                                                         // 64-bit: [4..5] their steps, [6..7] flattened steps T, [8..9] own tiles NT
-            CP_HIP(hipMemsetAsync(Wk.counts.p + 2, 0, 8 * sizeof(int32_t), s));
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
-                hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, Wk.counts.p + 2,               \
+                hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
-                Wk.o_tS0l.p, Wk.counts.p + 3, reinterpret_cast<unsigned long long *>(Wk.counts.p + 4), (int32_t)g_opt_own_min
+                Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)g_opt_own_min, (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
         }
-        int64_t T = 0, NT = 0;
+        RoundCounts P;                                   // the counts this round is sized with
+        if (spec) {
+            P = Wk.pred[(size_t)rd];
+            // buffers from the prediction (grown only here; k_round_finish checks the true totals against them)
+            Wk.ensure_own((size_t)grow(P.NT));
+            Wk.ensure_flat((size_t)grow(P.T));
+        }
         {
-            // both scans read their element count on the device: ONE host sync per round brings back every count and total
+            // both scans read their element count on the device
             ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
-            exclusive_scan_i32_devn(Wk.len.p, Wk.offs.p, Wk.counts.p + 2, R.ntask, reinterpret_cast<int64_t *>(Wk.counts.p + 6), Wk.scratch, s);
+            exclusive_scan_i32_devn(Wk.len.p, Wk.offs.p, &rc->nlong, R.ntask, &rc->T, Wk.scratch, s);
             if (own_tiles)
-                exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, Wk.counts.p + 3, std::min<int64_t>(R.ntask, (int64_t)Wk.o_ntl.n),
-                                        reinterpret_cast<int64_t *>(Wk.counts.p + 8), Wk.scratch, s);
+                exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, std::min<int64_t>(R.ntask, (int64_t)Wk.o_ntl.n), &rc->NT, Wk.scratch, s);
+            hipLaunchKernelGGL(k_round_finish, dim3(1), dim3(1), 0, s, rc, spec ? (int64_t)Wk.loc.n : INT64_MAX, spec ? (int64_t)Wk.o_rec.n : INT64_MAX);
         }
-        {
-            int32_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            CP_HIP(hipMemcpyAsync(hc, Wk.counts.p + 2, sizeof(hc), hipMemcpyDeviceToHost, s));
+        if (!spec) {
+            CP_HIP(hipMemcpyAsync(&P, rc, sizeof(P), hipMemcpyDeviceToHost, s));
             CP_HIP(hipStreamSynchronize(s));
-            nlong = hc[0]; nown = hc[1];
-            memcpy(&own_steps, &hc[2], sizeof(own_steps));
-            memcpy(&T, &hc[4], sizeof(T));
-            memcpy(&NT, &hc[6], sizeof(NT));
+            Wk.ensure_own((size_t)P.NT);
+            Wk.ensure_flat((size_t)P.T);
         }
-        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld long=%d own=%d T=%lld NT=%lld\n", R.isA, R.tau, (long long)R.ntask, nlong, nown, (long long)T, (long long)NT);
-        if (nlong <= 0 && nown <= 0) continue;
-        if (nown > 0 && NT > 0) {
+        used[(size_t)rd] = P;
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld %s long=%d own=%d T=%lld NT=%lld\n", R.isA, R.tau, (long long)R.ntask,
+                                   spec ? "predicted" : "exact", P.nlong, P.nown, (long long)P.T, (long long)P.NT);
+        if (P.nown > 0 && P.NT > 0) {
             // ---- long tasks with tiles of their own: map, stream + evaluate, merge
-            if (Wk.o_rec.n < (size_t)NT) {
-                Wk.o_rec.alloc((size_t)NT); Wk.o_task.alloc((size_t)NT); Wk.o_tileS.alloc((size_t)NT); Wk.o_tilePS.alloc((size_t)NT + 1);
-                Wk.o_part.alloc((size_t)NT);
-                if (hyp) { Wk.o_tileS2.alloc((size_t)NT); Wk.o_tilePS2.alloc((size_t)NT + 1); }
-            }
-            if (hyp && Wk.o_tileS2.n < (size_t)NT) { Wk.o_tileS2.alloc(Wk.o_tileS.n); Wk.o_tilePS2.alloc(Wk.o_tileS.n + 1); }
+            const int64_t gNT = spec ? (int64_t)Wk.o_rec.n : P.NT, gown = spec ? grow(P.nown) : P.nown;      // (capacity >= the true NT, checked)
             if (g_opt_dbg & 128) {                // poison what this block must write before it reads
                 int pat = (g_opt_dbg & 256) ? 0x00 : 0x7F;
                 CP_HIP(hipMemsetAsync(Wk.o_part.p, pat, Wk.o_part.bytes(), s));
-                CP_HIP(hipMemsetAsync(Wk.o_tileS.p, pat, sizeof(int32_t) * (size_t)NT, s));
-                CP_HIP(hipMemsetAsync(Wk.o_rec.p, pat, sizeof(int4) * (size_t)NT, s));
-                if (hyp) CP_HIP(hipMemsetAsync(Wk.o_tileS2.p, pat, sizeof(int32_t) * (size_t)NT, s));
+                CP_HIP(hipMemsetAsync(Wk.o_tileS.p, pat, Wk.o_tileS.bytes(), s));
+                CP_HIP(hipMemsetAsync(Wk.o_rec.p, pat, Wk.o_rec.bytes(), s));
+                if (hyp) CP_HIP(hipMemsetAsync(Wk.o_tileS2.p, pat, Wk.o_tileS2.bytes(), s));
             }
-            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(NT, 256)), dim3(256), 0, s, Wk.o_toffs.p, (int64_t)nown, NT, Wk.o_tdesc.p, Wk.o_rlen.p,
-                               Wk.o_rec.p, Wk.o_task.p);
+            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(gNT, 256)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p);
             {
-                ProfScope ps(PROF_OWN, s, (double)own_steps * (4.0 * (avg_deg + self_deg) + 24.0));      // same bytes per step as dp_lpass
-#define LO_ARGS R.isA, NT, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr,            \
+                ProfScope ps(PROF_OWN, s, (double)P.own_steps * step_bytes);      // same bytes per step as dp_lpass
+#define LO_ARGS R.isA, rc, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr,            \
                 Wk.o_tileS.p, Wk.o_tileS2.p, Wk.o_rec.p, W, M, alpha
-                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true>), dim3((unsigned)cdiv(NT, 4)), dim3(256), 0, s, LO_ARGS, Wk.o_part.p);
-                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false>), dim3((unsigned)cdiv(NT, 4)), dim3(256), 0, s, LO_ARGS,
+                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true>), dim3((unsigned)cdiv(gNT, 4)), dim3(256), 0, s, LO_ARGS, Wk.o_part.p);
+                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false>), dim3((unsigned)cdiv(gNT, 4)), dim3(256), 0, s, LO_ARGS,
                                             reinterpret_cast<Best<TC, false> *>(Wk.o_part.p));
 #undef LO_ARGS
             }
+            note(rd, 0);
             {
-                ProfScope ps(PROF_CARRY, s, 12.0 * (double)NT);
-                exclusive_scan_i32(Wk.o_tileS.p, Wk.o_tilePS.p, NT, Wk.scratch, s);
-                if (hyp) exclusive_scan_i32(Wk.o_tileS2.p, Wk.o_tilePS2.p, NT, Wk.scratch, s);
+                ProfScope ps(PROF_CARRY, s, 12.0 * (double)P.NT);
+                const int32_t *ntp = reinterpret_cast<const int32_t *>(&rc->NT);       // (NT < 2^31: the low word)
+                exclusive_scan_i32_devn(Wk.o_tileS.p, Wk.o_tilePS.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
+                if (hyp) exclusive_scan_i32_devn(Wk.o_tileS2.p, Wk.o_tilePS2.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
             }
             {
-                ProfScope ps(PROF_FIX, s, 24.0 * (double)NT);
-                bool wide = NT > 64 * (int64_t)nown;             // on average more than 64 tiles per task: one block per task
-#define FO_ARGS (int64_t)nown, Wk.o_toffs.p
+                ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
+                bool wide = P.NT > 64 * (int64_t)P.nown;         // on average more than 64 tiles per task: one block per task
+#define FO_ARGS rc, Wk.o_toffs.p
 #define FO_TAIL Wk.o_tdesc.p, Wk.o_tb.p
                 if (hyp) {
-                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3((unsigned)nown), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3((unsigned)gown), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
                                                  Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3((unsigned)cdiv((int64_t)nown, 4)), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3((unsigned)cdiv(gown, 4)), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
                                             FO_TAIL, Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
                 } else {
                     const Best<TC, false> *pp = reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p);
-                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3((unsigned)nown), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3((unsigned)gown), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
                                                  (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3((unsigned)cdiv((int64_t)nown, 4)), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3((unsigned)cdiv(gown, 4)), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
                                             (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
                 }
 #undef FO_ARGS
@@ -1257,81 +1301,64 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
             }
             CP_HIP(hipGetLastError());
         }
-        if (nlong <= 0 || T <= 0) continue;
-        R.ntask = nlong;                            // from here on the round consists of the flattened tasks only
-        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld T=%lld\n", R.isA, R.tau, (long long)R.ntask, (long long)T);
-        int64_t ntile = cdiv(T, LT);
-        Wk.loc.ensure((size_t)T);
-        if (hyp) Wk.loc2.ensure((size_t)T);
-        if (Wk.tileS.n < (size_t)ntile) {
-            Wk.tileS.alloc((size_t)ntile); Wk.tilePS.alloc((size_t)ntile + 1); Wk.tile_t0.alloc((size_t)ntile);
-            Wk.partL.alloc((size_t)ntile); Wk.partR.alloc((size_t)ntile); Wk.taskR.alloc((size_t)ntile);
-            Wk.open_list.alloc((size_t)ntile); Wk.fix_list.alloc((size_t)ntile); Wk.tile_rec.alloc((size_t)ntile);
-            if (hyp) { Wk.tileS2.alloc((size_t)ntile); Wk.tilePS2.alloc((size_t)ntile + 1); }
-        }
-        if (hyp && Wk.tileS2.n < (size_t)ntile) { Wk.tileS2.alloc(Wk.tileS.n); Wk.tilePS2.alloc(Wk.tileS.n + 1); }
-        CP_HIP(hipMemsetAsync(Wk.taskR.p, 0xFF, sizeof(int64_t) * (size_t)ntile, s));
-        CP_HIP(hipMemsetAsync(Wk.counts.p, 0, 2 * sizeof(int32_t), s));
+        if (P.nlong <= 0 || P.T <= 0) continue;
+        // ---- from here on the round consists of the flattened tasks only (their number: rc->nlong)
+        const int64_t gtile = spec ? (int64_t)Wk.tileS.n : cdiv(P.T, LT);      // (capacity >= the true tile count, checked)
         if (g_opt_dbg & 128) {                    // poison everything a round must write before it reads
             int pat = (g_opt_dbg & 256) ? 0x00 : 0x7F;
-            CP_HIP(hipMemsetAsync(Wk.loc.p, pat, sizeof(int32_t) * (size_t)T, s));
-            if (hyp) CP_HIP(hipMemsetAsync(Wk.loc2.p, pat, sizeof(int32_t) * (size_t)T, s));
+            CP_HIP(hipMemsetAsync(Wk.loc.p, pat, Wk.loc.bytes(), s));
+            if (hyp) CP_HIP(hipMemsetAsync(Wk.loc2.p, pat, Wk.loc2.bytes(), s));
             CP_HIP(hipMemsetAsync(Wk.partL.p, pat, Wk.partL.bytes(), s));
             CP_HIP(hipMemsetAsync(Wk.partR.p, pat, Wk.partR.bytes(), s));
-            CP_HIP(hipMemsetAsync(Wk.tileS.p, pat, sizeof(int32_t) * (size_t)ntile, s));
-            if (hyp) CP_HIP(hipMemsetAsync(Wk.tileS2.p, pat, sizeof(int32_t) * (size_t)ntile, s));
+            CP_HIP(hipMemsetAsync(Wk.tileS.p, pat, Wk.tileS.bytes(), s));
+            if (hyp) CP_HIP(hipMemsetAsync(Wk.tileS2.p, pat, Wk.tileS2.bytes(), s));
         }
-        hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, Wk.offs.p, R.ntask, ntile, T, Wk.tdesc.p, Wk.tile_t0.p,
-                           Wk.tile_rec.p, (int)((g_opt_dbg & 32) != 0));
+        hipLaunchKernelGGL(k_tile_t0, dim3((unsigned)cdiv(gtile, 256)), dim3(256), 0, s, rc, Wk.offs.p, Wk.tdesc.p, Wk.tile_t0.p,
+                           Wk.tile_rec.p, (int)((g_opt_dbg & 32) != 0), Wk.taskR.p);
         {
-            // algorithmic bytes of one launch (DESIGN.md section 5): per flattened step the stepped column's link
+            // algorithmic bytes of one launch (DESIGN.md section 6): per flattened step the stepped column's link
             // entries (4 B x N/n, plus 4 B x nonempty-rows/n for hyperedge costs), its colptr entry (8 B), the
             // candidate's previous-layer cost (8 B) and the task-descriptor share (offsets/B/anchor/row, amortised 8 B)
-            ProfScope ps(PROF_EXPAND, s, (double)T * (4.0 * (avg_deg + self_deg) + 24.0));
-#define LP_ARGS R, T, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,           \
+            ProfScope ps(PROF_EXPAND, s, (double)P.T * step_bytes);
+#define LP_ARGS R, rc, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,           \
                 hyp ? A->flast.p : (const int32_t *)nullptr, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.loc.p, Wk.loc2.p, Wk.tileS.p, Wk.tileS2.p,     \
                 Wk.taskR.p, Wk.tile_t0.p, Wk.tile_rec.p, W, M, alpha
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p, Wk.partL.p);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(ntile, 4)), dim3(256), 0, s, LP_ARGS,
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, true>), dim3((unsigned)cdiv(gtile, 4)), dim3(256), 0, s, LP_ARGS, Wk.partR.p, Wk.partL.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass<TC, false>), dim3((unsigned)cdiv(gtile, 4)), dim3(256), 0, s, LP_ARGS,
                                         reinterpret_cast<Best<TC, false> *>(Wk.partR.p), reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
 #undef LP_ARGS
         }
+        note(rd, 1);
         {
-            ProfScope ps(PROF_CARRY, s, 12.0 * (double)ntile);
-            exclusive_scan_i32(Wk.tileS.p, Wk.tilePS.p, ntile, Wk.scratch, s);
-            if (hyp) exclusive_scan_i32(Wk.tileS2.p, Wk.tilePS2.p, ntile, Wk.scratch, s);
+            ProfScope ps(PROF_CARRY, s, 12.0 * (double)cdiv(P.T, LT));
+            exclusive_scan_i32_devn(Wk.tileS.p, Wk.tilePS.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scratch, s);
+            if (hyp) exclusive_scan_i32_devn(Wk.tileS2.p, Wk.tilePS2.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scratch, s);
         }
-        unsigned wgrid = (unsigned)std::min<int64_t>(cdiv(ntile, 4), 8192);     // the wave kernels walk work lists
+        unsigned wgrid = (unsigned)std::min<int64_t>(cdiv(gtile, 4), 8192);     // the wave kernels walk work lists
         {
             ProfScope ps(PROF_EVAL, s, 0.0);
-#define SP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.taskR.p, Wk.tileS.p, Wk.tileS2.p
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, true>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
-                               Wk.partR.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.open_list.p, Wk.fix_list.p, Wk.counts.p, Wk.tile_rec.p);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, false>), dim3((unsigned)cdiv(ntile, 256)), dim3(256), 0, s, SP_ARGS,
+#define SP_ARGS R, rc, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, Wk.tb.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.taskR.p, Wk.tileS.p, Wk.tileS2.p
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, true>), dim3((unsigned)cdiv(gtile, 256)), dim3(256), 0, s, SP_ARGS,
+                               Wk.partR.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.open_list.p, Wk.fix_list.p, Wk.tile_rec.p);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_span_short<TC, false>), dim3((unsigned)cdiv(gtile, 256)), dim3(256), 0, s, SP_ARGS,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partR.p), W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                               Wk.open_list.p, Wk.fix_list.p, Wk.counts.p, Wk.tile_rec.p);
+                               Wk.open_list.p, Wk.fix_list.p, Wk.tile_rec.p);
 #undef SP_ARGS
-            if (g_opt_dbg & 16) {
-                int32_t hc[2] = {0, 0};
-                CP_HIP(hipMemcpyAsync(hc, Wk.counts.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-                CP_HIP(hipStreamSynchronize(s));
-                fprintf(stderr, "  span lists: isA=%d tau=%d ntile=%lld open_long=%d fix_long=%d\n", R.isA, R.tau, (long long)ntile, hc[0], hc[1]);
-            }
-#define OP_ARGS R, T, ntile, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.tilePS.p
+#define OP_ARGS R, rc, Wk.offs.p, Wk.tdesc.p, Wk.tS0l.p, A->pos32.p, Wk.loc.p, Wk.loc2.p, Wk.tile_t0.p, Wk.tilePS.p
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, true>), dim3(wgrid), dim3(256), 0, s, OP_ARGS, Wk.tilePS2.p, W, M, alpha, Wk.partL.p,
-                               Wk.open_list.p, Wk.counts.p);
+                               Wk.open_list.p);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_open<TC, false>), dim3(wgrid), dim3(256), 0, s, OP_ARGS, (const int64_t *)nullptr, W, M, alpha,
-                               reinterpret_cast<Best<TC, false> *>(Wk.partL.p), Wk.open_list.p, Wk.counts.p);
+                               reinterpret_cast<Best<TC, false> *>(Wk.partL.p), Wk.open_list.p);
 #undef OP_ARGS
         }
         {
-            ProfScope ps(PROF_FIX, s, 8.0 * (double)ntile);
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
-                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.fix_list.p, Wk.counts.p,
+            ProfScope ps(PROF_FIX, s, 8.0 * (double)cdiv(P.T, LT));
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, true>), dim3(wgrid), dim3(256), 0, s, rc, Wk.offs.p, Wk.taskR.p,
+                               Wk.partL.p, Wk.partR.p, Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.fix_list.p,
                                Wk.tile_rec.p, Wk.tilePS.p, Wk.tilePS2.p, Wk.tS0l.p, M);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3(wgrid), dim3(256), 0, s, ntile, Wk.offs.p, Wk.taskR.p,
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix<TC, false>), dim3(wgrid), dim3(256), 0, s, rc, Wk.offs.p, Wk.taskR.p,
                                reinterpret_cast<const Best<TC, false> *>(Wk.partL.p), reinterpret_cast<const Best<TC, false> *>(Wk.partR.p),
-                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.fix_list.p, Wk.counts.p,
+                               Wk.tdesc.p, Wk.tb.p, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.fix_list.p,
                                Wk.tile_rec.p, Wk.tilePS.p, (const int64_t *)nullptr, (const int32_t *)nullptr, M);
         }
         CP_HIP(hipGetLastError());
@@ -1344,6 +1371,64 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
     CP_HIP(hipGetLastError());
+    // ---- the true counts of every round: the next layer's prediction, this layer's verdict
+    std::vector<RoundCounts> got((size_t)NR);
+    CP_HIP(hipMemcpyAsync(got.data(), Wk.rc.p, sizeof(RoundCounts) * (size_t)NR, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    bool ok = true;
+    for (int rd = 0; rd < NR; rd++) {
+        const RoundCounts &g = got[(size_t)rd], &u = used[(size_t)rd];
+        CP_REQUIRE(!(g.err && !spec), CP_EINTERNAL, "DP work list overflow");
+        if (g.err) ok = false;                                                                  // a buffer was too small
+        if (g.nown > 0 && g.NT > 0 && !(u.nown > 0 && u.NT > 0)) ok = false;                    // a stage was skipped
+        if (g.nlong > 0 && g.T > 0 && !(u.nlong > 0 && u.T > 0)) ok = false;
+    }
+    if (ok) {
+        for (auto &pt : patches) {
+            const RoundCounts &g = got[(size_t)pt.rd];
+            if (pt.idx < g_prof_pending.size())
+                g_prof_pending[pt.idx].bytes = (pt.kind == 0 ? (double)g.own_steps : (double)g.T) * step_bytes;
+        }
+        Wk.pred = got; Wk.pred_ok = true; Wk.pred_rlo = rlo; Wk.pred_rhi = rhi;
+    }
+    return ok;
+}
+
+template <typename TC>
+void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_,
+                    int64_t rlo, int64_t rhi)
+{
+    auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
+    int64_t n = A->n;
+    bool hyp = M.kind == CP_MODEL_HYPEREDGE_CUT;
+    int nbits = 1;
+    while (((int64_t)1 << nbits) <= n) nbits++;
+    CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
+    if (Wk.n != n || Wk.hyp != hyp) {
+        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false;
+        size_t plane = (size_t)nbits * (size_t)(n + 1);
+        Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
+        if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
+        int64_t mx = n;
+        for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n, 0, n); if (R.ntask > mx) mx = R.ntask; }
+        Wk.max_tasks = mx > 0 ? mx : 1;
+        size_t mt = (size_t)Wk.max_tasks;
+        Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);
+        if (hyp) Wk.tS0l.alloc(mt);
+        // tasks with tiles of their own have >= own_min >= 64 candidates; the ranges of one plane and round overlap in their end
+        // points only: at most n / 64 + (rectangles) of them per plane -- (n / 32 + 64) per plane is a safe cap (k_setup_short guards it)
+        size_t mo = (size_t)(n / 32 + 64) * (size_t)nbits + 1024;
+        if (mo > mt) mo = mt;
+        Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1);
+        if (hyp) Wk.o_tS0l.alloc(mo);
+        Wk.rc.alloc((size_t)NBMAX + 2);
+    }
+    bool spec = Wk.pred_ok && Wk.pred_rlo == rlo && Wk.pred_rhi == rhi && !g_opt_nospec;
+    if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;
+    // the prediction missed (a stage that had been empty, or a buffer too small): the same layer again with exact counts
+    g_spec_redo++;
+    bool ok = run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, false);
+    CP_REQUIRE(ok, CP_EINTERNAL, "DP layer failed with exact counts");
 }
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }

@@ -31,7 +31,7 @@ CP_I64, CP_F64 = 0, 1
 CP_COMBINE_SUM, CP_COMBINE_MAX = 0, 1
 CP_ORDER_SPLITTER, CP_ORDER_CHUNKER = 0, 1
 CP_MAX_R = 4
-CP_OK, CP_EINVAL, CP_INFEASIBLE, CP_EHIP, CP_EUNSUPPORTED = range(5)
+CP_OK, CP_EINVAL, CP_INFEASIBLE, CP_EHIP, CP_EUNSUPPORTED, CP_EINTERNAL = range(6)
 
 
 class cp_component_t(C.Structure):

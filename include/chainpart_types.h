@@ -31,6 +31,7 @@ extern "C" {
                                 (DynamicSplitter.jl:217-222) */
 #define CP_EHIP          3   /* HIP / RCCL runtime error */
 #define CP_EUNSUPPORTED  4   /* (method, model) pair has no device path; nothing written */
+#define CP_EINTERNAL     5   /* an internal invariant failed (a bug in the library): nothing valid written */
 
 /* cost element type Tc (= the model's Tv) */
 #define CP_I64 0
