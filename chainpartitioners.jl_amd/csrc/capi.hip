@@ -442,6 +442,8 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "short_e")) { g_opt_short_e = value; return CP_OK; }
     if (!strcmp(name, "rpass_ch")) { int64_t v = 16; while (v < value && v < 4096) v <<= 1; g_opt_rpass_ch = v; return CP_OK; }
     if (!strcmp(name, "prof_only")) { g_prof_only = (int)value; return CP_OK; }
+    if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
+    if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     set_error("unknown option");

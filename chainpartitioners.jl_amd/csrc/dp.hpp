@@ -38,6 +38,7 @@ int32_t run_plaid_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order
 template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
+extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <= gap_tau (-1: none) for tasks of >= gap_min candidates
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
 extern int64_t g_opt_rpass_ch;                 // columns per wave in k_rpass_wave (power of two >= 16)

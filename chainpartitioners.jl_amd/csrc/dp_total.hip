@@ -54,6 +54,10 @@ struct RoundDesc {
     int64_t tskip[36];          // ... and start at linear index tskip[b] of that plane (row-tiled runs skip rows left of the tile)
     int64_t a_r0, a_nmain;      // round A: rows a_r0 .. a_r0 + a_nmain - 1, then the `extra` rows (ancestors outside the tile)
     int64_t extra[64];
+    // round A also takes the LAST row n in every bit plane above its lowest one (tasks after the extra rows): no row lies to
+    // its right, so nothing bounds the rows next to it from the left; with opt[b][n] known first, they start there instead of
+    // at the block start -- which every round would otherwise re-scan (n is not a power of two: ~n steps per round)
+    int32_t nlast, last_b[31];
 };
 
 // Per-round counters, on the device (one record per round, kept for the whole layer).  Kernels read their loop bounds from
@@ -64,11 +68,15 @@ struct RoundCounts {
     unsigned long long own_steps;     // steps of the latter
     int64_t T, NT;                    // flattened steps / own tiles (scan totals)
     int32_t ntile, err;               // cdiv(T, LT); 1: a buffer sized from the prediction is too small (the layer is redone)
+    int32_t n_wide, _pad;             // own-tiled tasks of more than FIX_SERIAL tiles (k_fix_own_lane -> k_fix_own)
 };
 
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
 {
-    if (R.isA) { r = t < R.a_nmain ? R.a_r0 + t : R.extra[t - R.a_nmain]; b = __ffsll((long long)r) - 1; return; }
+    if (R.isA) {
+        if (t >= R.a_nmain + R.nextra) { r = R.n; b = R.last_b[t - R.a_nmain - R.nextra]; return; }
+        r = t < R.a_nmain ? R.a_r0 + t : R.extra[t - R.a_nmain]; b = __ffsll((long long)r) - 1; return;
+    }
     int bb = R.tau + 1;
     while (t >= R.tbase[bb + 1]) bb++;
     int64_t l = t - R.tbase[bb] + R.tskip[bb];
@@ -185,6 +193,39 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     }
 }
 
+// ------------------------------------------------------------------ the last row n in the planes above its lowest bit
+// anchors of its round-A tasks: out[b] = #{q in columns [r_b, n) : prev[q] < r_b}, out[32 + b] = #{rows with last column in
+// [r_b, n) and first column >= r_b} (hyperedge costs), r_b = n with the bits below b cleared.  Entry q lies in a column >= r_b
+// iff q >= pos[r_b].  Then the rows are marked final: the round of ctz(n) skips them.
+__global__ void __launch_bounds__(256) k_last_row_counts(RoundDesc R, const int32_t *__restrict__ pos, const int32_t *__restrict__ prev,
+                                                         const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst, int32_t *__restrict__ out,
+                                                         uint8_t *__restrict__ fin)
+{
+    __shared__ int32_t s_acc[64];
+    if (threadIdx.x < 64) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = R.n, n1 = n + 1;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)R.nlast) fin[(int64_t)R.last_b[threadIdx.x] * n1 + prow(n, n)] = 1;
+    for (int pass = 0; pass < (lpos ? 2 : 1); pass++) {
+        const int32_t *cp = pass ? lpos : pos, *arr = pass ? lfirst : prev;
+        for (int i = 0; i < R.nlast; i++) {                 // (the ranges are nested; together at most 2 N entries)
+            const int64_t rb = (n >> R.last_b[i]) << R.last_b[i];
+            int32_t c = 0;
+            for (int64_t q = (int64_t)cp[rb] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x, q1 = cp[n]; q < q1; q += (int64_t)gridDim.x * blockDim.x) {
+                int32_t v = arr[q];
+                c += pass ? (v >= rb) : (v < rb);
+            }
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_acc[pass * 32 + i], c);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_acc[threadIdx.x]) {
+        int pass = threadIdx.x >> 5, i = threadIdx.x & 31;
+        if (i < R.nlast) atomicAdd(&out[pass * 32 + R.last_b[i]], s_acc[threadIdx.x]);
+    }
+}
+
 // ------------------------------------------------------------------ task setup
 // element 0 of a task is the candidate p = B (its count = anchor + right part); elements i >= 1 are the
 // left steps p = B - i.  Round A: B = r is virtual (not a candidate), anchor 0.
@@ -202,14 +243,14 @@ __global__ void __launch_bounds__(256) k_setup(RoundDesc R, const int32_t *__res
     if (zero_cr_only) { cr[(int64_t)b * n1 + PR(r)] = 0; if (crl) crl[(int64_t)b * n1 + PR(r)] = 0; return; }
     int64_t B, a, S0, S0l = 0;
     if (R.isA) {
-        B = r; a = r - ((int64_t)1 << b); S0 = 0;
+        B = r; a = r - ((int64_t)1 << b); S0 = 0;           // (zero_cr_only is the only use of this kernel in round A)
     } else {
         int64_t rb = (r >> b) << b;
         int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
         B = opt[(int64_t)b * n1 + PR(rL)];
         S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
         if (tS0l) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
-        a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + PR(rR)] : rb - ((int64_t)1 << b);
+        a = (rR - rb) < ((int64_t)1 << b) ? (int64_t)opt[(int64_t)b * n1 + PR(rR <= R.n ? rR : R.n)] : rb - ((int64_t)1 << b);
         if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
     }
     tdesc[t] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);      // one 16-byte record per task
@@ -293,7 +334,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
                                                       unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
-                                                      int32_t *__restrict__ err)
+                                                      int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -302,16 +343,24 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
     if (live) {
         decode_task(R, t, r, b);
+        if (fin && !R.isA && fin[(int64_t)b * (R.n + 1) + prow(r, R.n)]) live = false;      // finished by a gap pass of an earlier round
+    }
+    if (live) {
         int64_t n1 = R.n + 1;
         if (R.isA) {
-            B = r; a = r - ((int64_t)1 << b);
+            // B = r_b is virtual (not a candidate).  Rows r == r_b: nothing lies right of B, anchor 0; the last row n in a
+            // plane above its lowest bit: the anchor is the count of the columns [r_b, n) (k_last_row_counts)
+            B = (r >> b) << b; a = B - ((int64_t)1 << b);
+            if (B != r) { S0 = last_s0[b]; if (HYP) S0l = last_s0[32 + b]; }
         } else {
             int64_t rb = (r >> b) << b;
             int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
             B = opt[(int64_t)b * n1 + PR(rL)];
             S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
             if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
-            a = ((rR - rb) < ((int64_t)1 << b) && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + PR(rR)] : rb - ((int64_t)1 << b);
+            // left end of the range: the winner of the right neighbour -- or, where that lies beyond the matrix, of the last
+            // row n (same rectangle; known since round A); the block start for the last row of a rectangle
+            a = (rR - rb) < ((int64_t)1 << b) ? (int64_t)opt[(int64_t)b * n1 + PR(rR <= R.n ? rR : R.n)] : rb - ((int64_t)1 << b);
             if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
         }
         int64_t L = 1 + (B - a);
@@ -505,9 +554,14 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // counts, no wave scan, no carry.  The run is streamed once in 256-entry blocks (the next 512 entries are in flight while
 // a block is counted); per block: four ballots, a per-lane popcount prefix, and one gather per step whose column starts
 // inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
-template <bool GE>
+// DET (gap passes, see k_gap_finish): the entries of the run with a value strictly between sp_lo and sp_hi ("specials") are
+// appended to the wave's list: s_es[i] = first step e whose candidate has the entry's column on its right (steps >= e count
+// it), s_v[i] = the value, tagged with `kind` in bit 31.  `ns` counts them (wave-uniform; only the first SMAX are stored).
+constexpr int SMAX = 31;
+template <bool GE, bool DET = false>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
-                                                int32_t thr, int lane, int32_t acc[4], int32_t sk[4], int head = 0)
+                                                int32_t thr, int lane, int32_t acc[4], int32_t sk[4], int head = 0, int32_t sp_lo = 0, int32_t sp_hi = 0,
+                                                int32_t *s_es = nullptr, int32_t *s_v = nullptr, int *ns_ = nullptr, int kind = 0)
 {
     const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
 #pragma unroll
@@ -535,6 +589,28 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
                       m2 = __ballot(pb + 2 < Q_hi && v.z >= thr); m3 = __ballot(pb + 3 < Q_hi && v.w >= thr); }
             else    { m0 = __ballot(pb < Q_hi && v.x < thr); m1 = __ballot(pb + 1 < Q_hi && v.y < thr);
                       m2 = __ballot(pb + 2 < Q_hi && v.z < thr); m3 = __ballot(pb + 3 < Q_hi && v.w < thr); }
+            if (DET) {
+                bool s0 = pb >= Q_lo && pb < Q_hi && v.x > sp_lo && v.x < sp_hi, s1 = pb + 1 >= Q_lo && pb + 1 < Q_hi && v.y > sp_lo && v.y < sp_hi;
+                bool s2 = pb + 2 >= Q_lo && pb + 2 < Q_hi && v.z > sp_lo && v.z < sp_hi, s3 = pb + 3 >= Q_lo && pb + 3 < Q_hi && v.w > sp_lo && v.w < sp_hi;
+                if (__ballot(s0 || s1 || s2 || s3)) {                 // wave-uniform, rare
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        unsigned long long m = __ballot(j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3);
+                        while (m) {
+                            int l = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            int32_t q = xc + 4 * l + j;               // position of the special entry (uniform)
+                            int32_t val = __shfl(j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w, l);
+                            int cnt = 0;                              // steps whose column starts behind q: the entry's column is step `cnt`
+#pragma unroll
+                            for (int k = 0; k < 4; k++) cnt += __popcll(__ballot(lane + 64 * k <= tl && sk[k] > q));
+                            int ns = *ns_;
+                            if (ns < SMAX && lane == 0) { s_es[ns] = cnt; s_v[ns] = (int32_t)(((uint32_t)val & 0x7fffffffu) | ((uint32_t)kind << 31)); }
+                            *ns_ = ns + 1;
+                        }
+                    }
+                }
+            }
             int32_t tot = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);                       // uniform
             int32_t P0 = __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
 #pragma unroll
@@ -557,13 +633,18 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
     }
 }
 
+// Gap passes (k_gap_finish) take the tasks of at most GAP_MAXLEN steps: one wave walks all tiles of a task.  The few longer
+// ones (rows next to the matrix end, whose ranges are not bounded from the right) stay ordinary own-tiled tasks.
+constexpr int GAP_MAXLEN = 64 * LT;
+
 // ------------------------------------------------------------------ long tasks with tiles of their own
 // A task with >= LT steps is cut into tiles counted from ITS OWN head (the last one partial): every tile lies in one task,
 // so all of them -- head and tail included -- take the uniform path: one contiguous run of the link array, suffix counts,
 // tile-local evaluation.  k_own_map: tile -> (task, tile index inside the task); k_lpass_own: one wave per tile;
 // k_fix_own: one wave per task merges its tiles (adding the counts made before each tile).
 __global__ void __launch_bounds__(256) k_own_map(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ toffs, const int4 *__restrict__ tdesc,
-                                                 const int32_t *__restrict__ rlen, int4 *__restrict__ rec, int32_t *__restrict__ tile_task)
+                                                 const int32_t *__restrict__ rlen, int4 *__restrict__ rec, int32_t *__restrict__ tile_task,
+                                                 const uint8_t *__restrict__ tb, int32_t *__restrict__ gap_hi, int tau, int64_t n)
 {
     const int64_t ntask = rc->nown, ntile = rc->NT;
     for (int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tile < ntile; tile += (int64_t)gridDim.x * blockDim.x) {
@@ -576,17 +657,32 @@ __global__ void __launch_bounds__(256) k_own_map(const RoundCounts *__restrict__
     int4 td = tdesc[lo];
     int32_t rest = rlen[lo] - kt * LT;                // steps of the task from this tile on
     int32_t tl = (rest < LT ? rest : LT) - 1;
-    rec[tile] = make_int4(td.x - kt * LT, td.z, td.w, (tl << 1) | (kt == 0 ? 1 : 0));      // {column of step 0, row, pos[row], tl | head}
+    // {column of step 0, row, pos[row], tl | tile of a gap task | head}
+    const bool isgap = gap_hi && rlen[lo] <= GAP_MAXLEN;
+    rec[tile] = make_int4(td.x - kt * LT, td.z, td.w, (tl << 2) | (isgap ? 2 : 0) | (kt == 0 ? 1 : 0));
     tile_task[tile] = (int32_t)lo;
+    if (isgap) {                                       // gap pass: rows (r - 2^tau, hi) of the rectangle are finished together
+        int64_t r = td.z, b = tb[lo];
+        int64_t hi = r + ((int64_t)1 << tau), re = (((r >> b) + 1) << b);
+        if (hi > re) hi = re;
+        if (hi > n + 1) hi = n + 1;
+        gap_hi[tile] = (int32_t)hi;
+    }
     }
 }
 
-template <typename TC, bool HYP>
+template <typename TC, bool HYP, bool GAP>
 __global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *__restrict__ rc, const int32_t *__restrict__ a_pos, const int32_t *__restrict__ a_next,
                                                    const int32_t *__restrict__ a_fpos, const int32_t *__restrict__ a_flast,
                                                    int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2, const int4 *__restrict__ a_rec,
-                                                   const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ part)
+                                                   const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ part,
+                                                   int tau, const int32_t *__restrict__ gap_hi, uint8_t *__restrict__ spec, int force_spec,
+                                                   Best<TC, HYP> *__restrict__ sub, int32_t *__restrict__ spv)
 {
+    // GAP (rounds tau <= gap_tau, see k_gap_finish): the tile is evaluated for ALL rows r' of (r - 2^tau, hi) at once: the counts
+    // taken here are those of the entries every such row counts (next >= hi - 1; last <= r - 2^tau), the candidates are valued
+    // with the task's own row (the rows differ by terms that do not depend on the candidate), and `spec` says whether the tile
+    // holds an entry that only some of the rows count.
     // (Tried: tiles visited in column order, one contiguous share of the order per XCD, so that the ~10 passes of the bit planes
     //  over a column meet in L2: 10 % off this kernel, less than the sort of the tile list costs.)
     // (No grid-stride loop here: it costs 14 VGPRs = two waves per SIMD.  The host launches one wave per tile of the buffer's
@@ -596,50 +692,338 @@ __global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *_
     if (tile >= rc->NT) return;
     int4 rec = a_rec[tile];
     int head = rec.w & 1;
-    int32_t tl = rec.w >> 1;
+    int32_t tl = rec.w >> 2;
     int32_t acc[4], acc2[4] = {0, 0, 0, 0}, sk[4], sk2[4];
-    interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk, head);
-    if (HYP) interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc2, sk2, head);
+    __shared__ int32_t s_es_all[4][2][SMAX + 1], s_v_all[4][2][SMAX + 1];      // the wave's specials: as found / sorted by step
+    int32_t(*s_es)[SMAX + 1] = s_es_all[threadIdx.x >> 6], (*s_v)[SMAX + 1] = s_v_all[threadIdx.x >> 6];
+    int ns = 0;
+    if (GAP && (rec.w & 2)) {
+        int32_t rL = rec.y - (1 << tau), hi1 = gap_hi[tile] - 1;
+        interior_stream<true, true>(a_next, a_pos, rec.x, tl, hi1, lane, acc, sk, head, rL, hi1, s_es[0], s_v[0], &ns, 0);
+        if (HYP) interior_stream<false, true>(a_flast, a_fpos, rec.x, tl, rL + 1, lane, acc2, sk2, head, rL, hi1, s_es[0], s_v[0], &ns, 1);
+        if (force_spec) ns = SMAX + 1;
+    } else {
+        interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk, head);
+        if (HYP) interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc2, sk2, head);
+    }
     int sel = tl >> 6;
     if (lane == (tl & 63)) {
         a_tileS[tile] = sel == 0 ? acc[0] : sel == 1 ? acc[1] : sel == 2 ? acc[2] : acc[3];
         if (HYP) a_tileS2[tile] = sel == 0 ? acc2[0] : sel == 1 ? acc2[1] : sel == 2 ? acc2[2] : acc2[3];
     }
     // tile-local evaluation (the costs are affine in the counts; k_fix_own adds the counts made before the tile)
-    Best<TC, HYP> best; best_clear(best);
+    Best<TC, HYP> cand[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {                       // increasing e = decreasing p: an earlier candidate wins ties
+    for (int k = 0; k < 4; k++) {
         int32_t e = lane + 64 * k;
+        best_clear(cand[k]);
         if (e <= tl && !(head && isA && e == 0)) {     // round A: the head element p = r is not a candidate
             int32_t p = rec.x - e;
             TC fv = dm_apply(M, alpha, (int64_t)(rec.y - p), (int64_t)(rec.z - sk[k]), (int64_t)acc[k], (int64_t)acc2[k]);
-            Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = p; c.nn = acc[k]; best_set_nl(c, acc2[k]);
-            best = better(best, c);
+            cand[k].v = cadd(W[p], fv); cand[k].p = p; cand[k].nn = acc[k]; best_set_nl(cand[k], acc2[k]);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {                  // wave arg-min; ties -> larger p
-        int src = (lane + o) & 63;
-        Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
-        if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
-        bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
-        if (lane + o < 64 && take) best = c;
+    if (GAP && ns > SMAX) {                             // too many specials: k_gap_finish walks the tile entry by entry
+        if (lane == 0) spec[tile] = 255;
+        return;
     }
-    if (lane == 0) part[tile] = best;
+    if (!GAP || ns == 0) {                              // one winner
+        Best<TC, HYP> best; best_clear(best);
+#pragma unroll
+        for (int k = 0; k < 4; k++) best = better(best, cand[k]);       // increasing e = decreasing p: an earlier candidate wins ties
+        for (int o = 32; o > 0; o >>= 1) {              // wave arg-min; ties -> larger p
+            int src = (lane + o) & 63;
+            Best<TC, HYP> c; best_clear(c); c.v = shfl64(best.v, src); c.p = __shfl(best.p, src); c.nn = __shfl(best.nn, src);
+            if (HYP) best_set_nl(c, __shfl(best_nl(best), src));
+            bool take = (best.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < best.v || (c.v == best.v && c.p > best.p)));
+            if (lane + o < 64 && take) best = c;
+        }
+        if (lane == 0) { part[tile] = best; if (GAP) spec[tile] = 0; }
+        return;
+    }
+    // GAP with specials: they cut the tile into segments of candidates that see the same specials on their right; every
+    // segment keeps a winner of its own (the rows weigh the segments differently): one segmented arg-min scan.
+    __threadfence_block();                              // (lane 0 wrote the list)
+    if (lane < ns) {                                    // sort by step: rank = number of specials in front
+        int32_t es_i = s_es[0][lane]; int rank = 0;
+        for (int j = 0; j < ns; j++) { int32_t es_j = s_es[0][j]; rank += (es_j < es_i) || (es_j == es_i && j < lane); }
+        s_es[1][rank] = es_i; s_v[1][rank] = s_v[0][lane];
+    }
+    __threadfence_block();
+    int seg[4] = {0, 0, 0, 0}, hd[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < ns; i++) {
+        int32_t es_i = s_es[1][i];                      // (uniform)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { seg[k] += (es_i <= lane + 64 * k); hd[k] |= (es_i == lane + 64 * k); }
+    }
+    if (lane == 0) hd[0] = 1;
+    const int64_t sbase = tile * (SMAX + 1);
+    if (lane <= ns) {                                   // segments without a candidate (two specials at one step, a special at step 0)
+        int32_t lo = lane == 0 ? 0 : s_es[1][lane - 1], hi = lane == ns ? tl + 1 : s_es[1][lane];
+        if (hi <= lo) { Best<TC, HYP> z; best_clear(z); sub[sbase + lane] = z; }
+    }
+    Best<TC, HYP> bcarry; best_clear(bcarry);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int32_t e = lane + 64 * k;
+        Best<TC, HYP> x = cand[k];
+        int f = hd[k];
+        wave_segmin<TC, HYP>(x, f, lane);
+        if (!f) x = better(bcarry, x);
+        {
+            Best<TC, HYP> nb; best_clear(nb); nb.v = shfl64(x.v, 63); nb.p = __shfl(x.p, 63); nb.nn = __shfl(x.nn, 63);
+            if (HYP) best_set_nl(nb, __shfl(best_nl(x), 63));
+            bcarry = nb;
+        }
+        int nh = __shfl_down(hd[k], 1), nh0 = __shfl(hd[k + 1], 0);
+        if (lane == 63) nh = nh0;
+        if (e <= tl && (e == tl || nh)) sub[sbase + seg[k]] = x;       // the last candidate of a segment holds its winner
+    }
+    if (lane < ns) spv[sbase + lane] = s_v[1][lane];
+    if (lane == 0) spec[tile] = (uint8_t)ns;
+}
+
+// ------------------------------------------------------------------ gap passes
+// The arg-min staircase of a rectangle jumps: between two neighbouring rows rL < rR of a round the winners B = opt[rL] and
+// a = opt[rR] can lie thousands of columns apart, and the divide and conquer re-scans that gap [a, B] once per level below.
+// In the rounds tau <= gap_tau a task with such a gap instead finishes EVERY row r' of (rL, hi), hi = min(rR, rectangle end,
+// n + 1), in one pass over the gap: each of them has its (rightmost) winner inside [a, B].
+//   nets(p, r') = nets(B, rL) + #{q in cols [rL, r') : prev[q] < B} + #{q in cols [p, B) : next[q] >= r'}
+// and the last term is the same for all these rows except for the entries with rL < next[q] < hi - 1 ("special": counted by
+// some rows only).  k_lpass_own<GAP> streams the gap once with the common threshold and flags the tiles holding specials; here
+// one wave per (task, 64 rows) gives every lane a row and walks the task's tiles in candidate order: a plain tile contributes
+// its winner (the same for all rows: their values differ by a row-only term plus cum(r') = the specials passed so far that
+// the row counts); a flagged tile is re-walked entry by entry with every lane counting for its own row.  Ties: strict <
+// in walking order = the larger p wins, as everywhere.  The rows are marked final (fin): later rounds skip them.
+template <bool GE>
+__device__ __forceinline__ int32_t gap_right_counts(const int32_t *__restrict__ cpos, const int32_t *__restrict__ arr, int32_t rL, int ck, int32_t thr,
+                                                    int32_t n, int lane)
+{
+    // #{entries of columns [rL, r') passing the test}, r' = rL + 1 + 64 ck + lane.  Coalesced: the columns of the earlier row
+    // chunks are summed by the whole wave; the wave's own 64 columns are one contiguous run of entries, flagged 64 at a time,
+    // and every lane counts the flags in front of the end of its column.
+    int32_t cfirst = rL + 64 * ck;
+    if (cfirst > n) cfirst = n;
+    int32_t c = 0;
+    for (int32_t q = cpos[rL] + lane, q1 = cpos[cfirst]; q < q1; q += 64) { int32_t v = arr[q]; c += GE ? (v >= thr) : (v < thr); }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    int32_t jn = cfirst + lane + 1, cl = cfirst + 64;
+    if (jn > n) jn = n;
+    if (cl > n) cl = n;
+    const int32_t myend = cpos[jn], e0 = cpos[cfirst], e1 = cpos[cl];
+    int32_t mine = 0;
+    for (int32_t base = e0; base < e1; base += 64) {
+        int32_t q = base + lane;
+        bool fl = false;
+        if (q < e1) { int32_t v = arr[q]; fl = GE ? (v >= thr) : (v < thr); }
+        unsigned long long m = __ballot(fl);
+        int32_t w = myend - base;
+        if (w > 0) mine += __popcll(w >= 64 ? m : (m & ((1ull << w) - 1ull)));
+    }
+    return c + mine;
+}
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n,
+                                                    const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
+                                                    const Best<TC, HYP> *__restrict__ sub, const int32_t *__restrict__ spv, const uint8_t *__restrict__ spec,
+                                                    const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ rlen,
+                                                    const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2,
+                                                    const int32_t *__restrict__ pos, const int32_t *__restrict__ next, const int32_t *__restrict__ prev,
+                                                    const int32_t *__restrict__ fpos, const int32_t *__restrict__ flast,
+                                                    const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
+                                                    const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                    int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nwork = (int64_t)rc->nown * nchunk, n1 = n + 1;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+        const int64_t t = w / nchunk;
+        const int ck = (int)(w - t * nchunk);
+        const int4 td = tdesc[t];                           // {B, anchor + right part of the task's own row, row r, pos[r]}
+        const int b = tb[t];
+        const int32_t B = td.x, r = td.z, posr = td.w, L = rlen[t];
+        if (L > GAP_MAXLEN) continue;                       // (wave-uniform) an ordinary own-tiled task: k_fix_own
+        const int32_t rL = r - (1 << tau);
+        int64_t hi64 = (int64_t)r + ((int64_t)1 << tau), re = ((((int64_t)r >> b) + 1) << b);
+        if (hi64 > re) hi64 = re;
+        if (hi64 > n + 1) hi64 = n + 1;
+        const int32_t hi = (int32_t)hi64;
+        const int32_t rr = rL + 1 + 64 * ck + lane;         // this lane's row
+        if (rL + 1 + 64 * ck >= hi) continue;               // (wave-uniform: the chunk lies beyond the gap's rows)
+        const bool valid = rr < hi;
+        const int32_t rcmp = valid ? rr : INT32_MAX;        // an invalid lane counts nothing
+        // right parts of the rows and the anchor (counts at (B, rL))
+        const int32_t Rr = gap_right_counts<false>(pos, prev, rL, ck, B, (int32_t)n, lane);
+        const int32_t Rr2 = HYP ? gap_right_counts<true>(lpos, lfirst, rL, ck, B, (int32_t)n, lane) : 0;
+        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)rL);
+        const int32_t anchor = nnopt[rwL], anchor2 = HYP ? nlopt[rwL] : 0;
+        // walk the tiles (their records are fetched 64 tiles at a time, one per lane; the winners of a tile with specials one
+        // segment per lane)
+        const int64_t k0 = toffs[t], k1 = toffs[t + 1];
+        const int64_t ps0 = tilePS[k0], ps20 = HYP ? tilePS2[k0] : 0;
+        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0;
+        int32_t cum = 0, cum2 = 0;
+        for (int64_t kb = k0; kb < k1; kb += 64) {
+        const int64_t km = kb + lane < k1 ? kb + lane : k1 - 1;
+        const int32_t m_base = (int32_t)(tilePS[km] - ps0), m_base2 = HYP ? (int32_t)(tilePS2[km] - ps20) : 0;
+        const int m_ns = spec[km];
+        Best<TC, HYP> m_part; best_clear(m_part);
+        if (m_ns == 0) m_part = part[km];
+        const int nb = (int)(k1 - kb < 64 ? k1 - kb : 64);
+        for (int i = 0; i < nb; i++) {
+            const int64_t k = kb + i;
+            const int32_t base = __shfl(m_base, i), base2 = HYP ? __shfl(m_base2, i) : 0;
+            const int ns = __shfl(m_ns, i);
+            if (ns <= SMAX) {
+                // plain tile: one winner; tile with ns specials: ns + 1 segment winners, a special between two segments
+                Best<TC, HYP> c; best_clear(c);
+                int32_t sv = 0;
+                if (ns == 0) {
+                    c.v = shfl64(m_part.v, i); c.p = __shfl(m_part.p, i); c.nn = __shfl(m_part.nn, i);
+                    if (HYP) best_set_nl(c, __shfl(best_nl(m_part), i));
+                } else {
+                    if (lane <= ns) c = sub[k * (SMAX + 1) + lane];
+                    if (lane < ns) sv = spv[k * (SMAX + 1) + lane];
+                }
+                for (int sg = 0; sg <= ns; sg++) {
+                    Best<TC, HYP> d = c;
+                    if (ns) { d.v = shfl64(c.v, sg); d.p = __shfl(c.p, sg); d.nn = __shfl(c.nn, sg); if (HYP) best_set_nl(d, __shfl(best_nl(c), sg)); }
+                    if (d.p >= 0) {
+                        int32_t lc = d.nn + base + cum, lc2 = HYP ? best_nl(d) + base2 + cum2 : 0;
+                        TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum), (int64_t)(base2 + cum2)));
+                        if (bp < 0 || v < bv) { bv = v; bp = d.p; bl = lc; bl2 = lc2; }
+                    }
+                    if (sg < ns) {                          // the candidates from here on have this special on their right
+                        const int32_t s1 = __shfl(sv, sg), val = s1 & 0x7fffffff;
+                        if (s1 >= 0) cum += (val >= rcmp);
+                        else cum2 += (valid && val < rr);
+                    }
+                }
+                continue;
+            }
+            // too many specials: every lane counts for its own row, entry by entry
+            const int head = k == k0 ? 1 : 0;
+            const int32_t pf = B - (int32_t)(k - k0) * LT;
+            int32_t tlk = L - (int32_t)(k - k0) * LT; tlk = (tlk < LT ? tlk : LT) - 1;
+            // pos[pf + 1 - j] and W[pf - j] of the tile's columns are fetched lane-strided; the entries come through 64-entry
+            // windows (one coalesced load each) and are handed to all lanes one at a time
+#define CP_SEL5(a_, i_) ((i_) < 64 ? a_[0] : (i_) < 128 ? a_[1] : (i_) < 192 ? a_[2] : (i_) < 256 ? a_[3] : a_[4])
+            int32_t pk[5], pk2[5] = {0, 0, 0, 0, 0}; TC wk[4];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                int32_t e = lane + 64 * j;
+                pk[j] = e <= tlk + 1 ? pos[pf + 1 - e] : 0;
+                if (HYP) pk2[j] = e <= tlk + 1 ? fpos[pf + 1 - e] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { int32_t e = lane + 64 * j; wk[j] = e <= tlk ? W[pf - e] : (TC)0; }
+            int32_t run = 0, run2 = 0;
+            int32_t wb = INT32_MAX, reg = 0, wb2 = INT32_MAX, reg2 = 0;
+            for (int32_t e = 0; e <= tlk; e++) {
+                const int32_t p = pf - e, e1 = e + 1;
+                const int32_t en = __shfl(CP_SEL5(pk, e), e & 63), st = __shfl(CP_SEL5(pk, e1), e1 & 63);      // pos[p + 1], pos[p]
+                if (!(head && e == 0)) {                    // step over column p (the head element steps over nothing)
+                    for (int32_t q = en - 1; q >= st; q--) {
+                        if (q < wb || q - wb > 63) { wb = q - 63; reg = wb + lane >= 0 ? next[wb + lane] : 0; }
+                        const int32_t x = __shfl(reg, q - wb);           // (every lane takes part: no short-circuit around a shuffle)
+                        run += (x >= rcmp);
+                    }
+                    if (HYP) {
+                        const int32_t en2 = __shfl(CP_SEL5(pk2, e), e & 63), st2 = __shfl(CP_SEL5(pk2, e1), e1 & 63);
+                        for (int32_t q = en2 - 1; q >= st2; q--) {
+                            if (q < wb2 || q - wb2 > 63) { wb2 = q - 63; reg2 = wb2 + lane >= 0 ? flast[wb2 + lane] : 0; }
+                            const int32_t x = __shfl(reg2, q - wb2);
+                            run2 += (valid && x < rr);
+                        }
+                    }
+                }
+                const TC wp = shfl64(e < 64 ? wk[0] : e < 128 ? wk[1] : e < 192 ? wk[2] : wk[3], e & 63);
+                int32_t lc = base + cum + run, lc2 = base2 + cum2 + run2;
+                TC v = cadd(wp, dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - st), (int64_t)lc, (int64_t)lc2));
+                if (bp < 0 || v < bv) { bv = v; bp = p; bl = lc; bl2 = lc2; }
+            }
+#undef CP_SEL5
+            // from here on the row also counts the specials of this tile it passed
+            cum += run - (int32_t)(tilePS[k + 1] - tilePS[k]);
+            if (HYP) cum2 += run2 - (int32_t)(tilePS2[k + 1] - tilePS2[k]);
+        }
+        }
+        if (valid) {
+            int64_t rw = (int64_t)b * n1 + PR((int64_t)rr);
+            opt[rw] = bp; nnopt[rw] = anchor + Rr + bl;
+            if (HYP) nlopt[rw] = anchor2 + Rr2 + bl2;
+            fin[rw] = 1;
+        }
+    }
+}
+
+// Merging the tiles of a task: one LANE per task looks at the tile count -- up to FIX_SERIAL: merged by the lane; more: appended
+// to the list k_fix_own walks (one wave or one block per task).  (Tried: k_lpass_own writing the winner of a single-tile task
+// itself -- the dependent loads at the end of every wave cost it more than the merge saves.)
+constexpr int FIX_SERIAL = 16;
+
+template <typename TC, bool HYP>
+__device__ __forceinline__ void fix_merge(Best<TC, HYP> &acc, Best<TC, HYP> c, int64_t base, int64_t base2, const DevModel<TC> &M)
+{
+    if (c.p >= 0) {
+        c.v = cadd(c.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, base, base2));
+        c.nn = (int32_t)(c.nn + base);
+        if (HYP) best_set_nl(c, (int32_t)(best_nl(c) + base2));
+    }
+    bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+    if (take) acc = c;
+}
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_fix_own_lane(RoundCounts *__restrict__ rc, const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
+                                                      const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ tS0l,
+                                                      const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2, DevModel<TC> M,
+                                                      int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
+                                                      int32_t *__restrict__ wide_list, const int32_t *__restrict__ rlen, int gap_round)
+{
+    const int64_t ntask = rc->nown;
+    int lane = threadIdx.x & 63;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < ntask; t0 += (int64_t)gridDim.x * blockDim.x) {      // wave-uniform
+        int64_t t = t0 + threadIdx.x;
+        int64_t k0 = 0, k1 = 0;
+        if (t < ntask && !(gap_round && rlen[t] <= GAP_MAXLEN)) { k0 = toffs[t]; k1 = toffs[t + 1]; }      // (gap tasks: k_gap_finish)
+        int64_t nt = k1 - k0;
+        bool wide = nt > FIX_SERIAL;
+        unsigned long long mw = __ballot(wide);
+        if (mw) {                                                   // wave-aggregated append
+            int32_t base = 0;
+            if (lane == 0) base = atomicAdd(&rc->n_wide, (int32_t)__popcll(mw));
+            base = __shfl(base, 0);
+            if (wide) wide_list[base + __popcll(mw & ((1ull << lane) - 1ull))] = (int32_t)t;
+        }
+        if (nt < 1 || wide) continue;
+        int4 td = tdesc[t];
+        int64_t S0 = td.y, S0l = HYP ? (int64_t)tS0l[t] : 0;
+        Best<TC, HYP> acc; best_clear(acc);
+        for (int64_t k = k0; k < k1; k++)                          // increasing k = decreasing p: larger p wins ties
+            fix_merge<TC, HYP>(acc, part[k], S0 + (tilePS[k] - tilePS[k0]), HYP ? S0l + (tilePS2[k] - tilePS2[k0]) : 0, M);
+        int64_t rw = (int64_t)tb[t] * n1 + PR((int64_t)td.z);
+        opt[rw] = acc.p; nnopt[rw] = acc.nn;
+        if (HYP) nlopt[rw] = best_nl(acc);
+    }
 }
 
 template <typename TC, bool HYP, int WPT>
 __global__ void __launch_bounds__(256) k_fix_own(const RoundCounts *__restrict__ rc, const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
                                                  const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ tS0l,
                                                  const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2, DevModel<TC> M,
-                                                 int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1)
+                                                 int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
+                                                 const int32_t *__restrict__ wide_list)
 {
     // WPT = 1: one wave per task (four tasks per block); WPT = 4: the whole block works on one task (rounds with a few
     // tasks of thousands of tiles each)
     __shared__ Best<TC, HYP> s_part[4];
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t ntask = rc->nown;
+    const int64_t nlist = rc->n_wide;
     // (the loop is block-uniform when WPT == 4: the barrier below is reached by the whole block)
-    for (int64_t t = WPT == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x; t < ntask; t += WPT == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x) {
+    for (int64_t i = WPT == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x; i < nlist; i += WPT == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x) {
+    int64_t t = wide_list[i];
     int64_t k0 = toffs[t], k1 = toffs[t + 1];
     int4 td = tdesc[t];
     int64_t S0 = td.y, S0l = HYP ? (int64_t)tS0l[t] : 0;
@@ -1072,7 +1456,11 @@ struct LayerWork {
     // tasks with tiles of their own (k_lpass_own)
     DBuf<int4> o_tdesc, o_rec;
     DBuf<uint8_t> o_tb;
-    DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2;
+    DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2, o_wide, o_hi;
+    DBuf<Best<TC, true>> o_sub;                         // gap passes: segment winners of the tiles with specials, [tile][SMAX + 1]
+    DBuf<int32_t> o_spv;                                // ... and the specials between them
+    DBuf<int32_t> last_s0;                              // anchors of the last row's round-A tasks ([b], [32 + b])
+    DBuf<uint8_t> o_spec, fin;                          // gap passes: flagged tiles; rows already final (per plane slot)
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
@@ -1082,7 +1470,8 @@ struct LayerWork {
     void ensure_own(size_t NT) {                        // per-tile arrays of the own-tiled tasks
         if (o_rec.n >= NT && o_rec.n > 0) return;
         size_t c = NT > 0 ? NT : 1;
-        o_rec.alloc(c); o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c);
+        o_rec.alloc(c); o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c); o_hi.alloc(c); o_spec.alloc(c);
+        if (g_opt_gap_tau >= 0) { o_sub.alloc(c * (SMAX + 1)); o_spv.alloc(c * (SMAX + 1)); }
         if (hyp) { o_tileS2.alloc(c); o_tilePS2.alloc(c + 1); }
     }
     void ensure_flat(size_t T) {                        // per-step and per-tile arrays of the flattened tasks
@@ -1131,7 +1520,13 @@ static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, in
                     if (r >= 1 && ((r >> b) & 1) && R.nextra < 64) R.extra[R.nextra++] = r;      // ctz(r) == b exactly
             }
         }
-        R.ntask = R.a_nmain + R.nextra;
+        R.nlast = 0;
+        if (n >= 1) {
+            int lowest = 0;
+            while (!((n >> lowest) & 1)) lowest++;
+            for (int b = lowest + 1; b < nbits; b++) if ((n >> b) & 1) R.last_b[R.nlast++] = b;
+        }
+        R.ntask = R.a_nmain + R.nextra + R.nlast;
         return;
     }
     int64_t rmin = rlo - ((int64_t)1 << tau), rmax = rhi + ((int64_t)1 << tau);
@@ -1194,6 +1589,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     const bool own_tiles = !(g_opt_dbg & 64);      // cp_set_option("dbg", 64): keep every long task in the flattened space
     const int NR = nbits + 1;
     CP_HIP(hipMemsetAsync(Wk.rc.p, 0, sizeof(RoundCounts) * (size_t)NR, s));
+    const bool gaps = own_tiles && g_opt_gap_tau >= 0;
+    CP_HIP(hipMemsetAsync(Wk.fin.p, 0, Wk.fin.bytes(), s));
     std::vector<RoundCounts> used((size_t)NR);          // what the host sized each round with
     memset(used.data(), 0, sizeof(RoundCounts) * (size_t)NR);
     struct Patch { size_t idx; int rd; int kind; };
@@ -1207,6 +1604,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         else make_round(R, false, nbits - rd, nbits, n, rlo, rhi);
         if (R.ntask <= 0) continue;
         RoundCounts *rc = Wk.rc.p + rd;
+        const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
         if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
@@ -1217,13 +1615,19 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
             if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
         }
+        if (R.isA && R.nlast > 0) {
+            CP_HIP(hipMemsetAsync(Wk.last_s0.p, 0, Wk.last_s0.bytes(), s));
+            hipLaunchKernelGGL(k_last_row_counts, dim3(1024), dim3(256), 0, s, R, A->pos32.p, A->prev.p, hyp ? A->lpos32.p : (const int32_t *)nullptr,
+                               hyp ? A->lfirst.p : (const int32_t *)nullptr, Wk.last_s0.p, Wk.fin.p);
+        }
         {
             // per task: four gathers from the plane arrays + the record; short tasks also step over their columns here
             ProfScope ps(PROF_SETUP, s, 29.0 * (double)R.ntask);
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
-                Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)g_opt_own_min, (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err
+                Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
+                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
@@ -1262,14 +1666,21 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 CP_HIP(hipMemsetAsync(Wk.o_rec.p, pat, Wk.o_rec.bytes(), s));
                 if (hyp) CP_HIP(hipMemsetAsync(Wk.o_tileS2.p, pat, Wk.o_tileS2.bytes(), s));
             }
-            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(gNT, 256)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p);
+            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(gNT, 256)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p,
+                               Wk.o_tb.p, gap ? Wk.o_hi.p : (int32_t *)nullptr, R.tau, n);
             {
                 ProfScope ps(PROF_OWN, s, (double)P.own_steps * step_bytes);      // same bytes per step as dp_lpass
 #define LO_ARGS R.isA, rc, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr,            \
                 Wk.o_tileS.p, Wk.o_tileS2.p, Wk.o_rec.p, W, M, alpha
-                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true>), dim3((unsigned)cdiv(gNT, 4)), dim3(256), 0, s, LO_ARGS, Wk.o_part.p);
-                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false>), dim3((unsigned)cdiv(gNT, 4)), dim3(256), 0, s, LO_ARGS,
-                                            reinterpret_cast<Best<TC, false> *>(Wk.o_part.p));
+#define LO_TAIL R.tau, Wk.o_hi.p, Wk.o_spec.p, (int)((g_opt_dbg & 512) != 0)
+                Best<TC, false> *sb0 = reinterpret_cast<Best<TC, false> *>(Wk.o_sub.p);
+                unsigned og = (unsigned)cdiv(gNT, 4);
+                Best<TC, false> *pp0 = reinterpret_cast<Best<TC, false> *>(Wk.o_part.p);
+                if (hyp) { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, true>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p);
+                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, false>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p); }
+                else     { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, true>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p);
+                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, false>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p); }
+#undef LO_TAIL
 #undef LO_ARGS
             }
             note(rd, 0);
@@ -1279,22 +1690,45 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 exclusive_scan_i32_devn(Wk.o_tileS.p, Wk.o_tilePS.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
                 if (hyp) exclusive_scan_i32_devn(Wk.o_tileS2.p, Wk.o_tilePS2.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
             }
+            if (gap) {
+                // every row of the gaps gets its winner: one wave per (task, 64 rows)
+                ProfScope ps(PROF_GAP, s, 24.0 * (double)P.NT);
+                const int nchunk = (int)std::max<int64_t>(1, ((int64_t)2 << R.tau) / 64);
+                unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * nchunk, 4), 16384);
+#define GF_ARGS R.tau, nchunk, rc, n, Wk.o_toffs.p
+#define GF_TAIL Wk.o_spec.p, Wk.o_tdesc.p, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->prev.p,                                \
+                hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr, hyp ? A->lpos32.p : (const int32_t *)nullptr,          \
+                hyp ? A->lfirst.p : (const int32_t *)nullptr, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p
+                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true>), dim3(gg), dim3(256), 0, s, GF_ARGS, Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, GF_TAIL);
+                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false>), dim3(gg), dim3(256), 0, s, GF_ARGS,
+                                            reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p),
+                                            Wk.o_spv.p, GF_TAIL);
+#undef GF_ARGS
+#undef GF_TAIL
+            }
             {
+                // (gap rounds: only the tasks too long for a gap pass are merged here)
                 ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
-                bool wide = P.NT > 64 * (int64_t)P.nown;         // on average more than 64 tiles per task: one block per task
+                // one lane per task: single tiles are final already, short tasks are merged on the spot, the rest is listed
+                bool wide = P.NT > 64 * (int64_t)P.nown;         // on average more than 64 tiles per task: one block per listed task
+                unsigned lgrid = (unsigned)std::min<int64_t>(cdiv(gown, 256), 4096), wgrid = (unsigned)std::min<int64_t>(wide ? gown : cdiv(gown, 4), 8192);
 #define FO_ARGS rc, Wk.o_toffs.p
 #define FO_TAIL Wk.o_tdesc.p, Wk.o_tb.p
                 if (hyp) {
-                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3((unsigned)gown), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
-                                                 Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3((unsigned)cdiv(gown, 4)), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
-                                            FO_TAIL, Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own_lane<TC, true>), dim3(lgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL, Wk.o_tS0l.p,
+                                       Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p, Wk.o_rlen.p, gap ? 1 : 0);
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
+                                                 Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
+                                            FO_TAIL, Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p);
                 } else {
                     const Best<TC, false> *pp = reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p);
-                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3((unsigned)gown), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
-                                                 (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3((unsigned)cdiv(gown, 4)), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
-                                            (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own_lane<TC, false>), dim3(lgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL, (const int32_t *)nullptr,
+                                       Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p, Wk.o_rlen.p, gap ? 1 : 0);
+                    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                                                 (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
+                                            (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p);
                 }
 #undef FO_ARGS
 #undef FO_TAIL
@@ -1417,11 +1851,13 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (hyp) Wk.tS0l.alloc(mt);
         // tasks with tiles of their own have >= own_min >= 64 candidates; the ranges of one plane and round overlap in their end
         // points only: at most n / 64 + (rectangles) of them per plane -- (n / 32 + 64) per plane is a safe cap (k_setup_short guards it)
-        size_t mo = (size_t)(n / 32 + 64) * (size_t)nbits + 1024;
+        int64_t mmin = std::max<int64_t>(2, std::min(g_opt_own_min, g_opt_gap_tau >= 0 ? g_opt_gap_min : g_opt_own_min));
+        size_t mo = (size_t)(2 * n / mmin + 64) * (size_t)nbits + 1024;
         if (mo > mt) mo = mt;
-        Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1);
+        Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1); Wk.o_wide.alloc(mo);
         if (hyp) Wk.o_tS0l.alloc(mo);
         Wk.rc.alloc((size_t)NBMAX + 2);
+        Wk.fin.alloc(plane); Wk.last_s0.alloc(64);
     }
     bool spec = Wk.pred_ok && Wk.pred_rlo == rlo && Wk.pred_rhi == rhi && !g_opt_nospec;
     if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;
