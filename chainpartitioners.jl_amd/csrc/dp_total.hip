@@ -69,6 +69,7 @@ struct RoundCounts {
     int64_t T, NT;                    // flattened steps / own tiles (scan totals)
     int32_t ntile, err;               // cdiv(T, LT); 1: a buffer sized from the prediction is too small (the layer is redone)
     int32_t n_wide, _pad;             // own-tiled tasks of more than FIX_SERIAL tiles (k_fix_own_lane -> k_fix_own)
+    int32_t n_glong, n_gslots;        // gap tasks of more than GAPSEG tiles and their segment slots (k_gap_finish -> k_gap_seg)
 };
 
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
@@ -633,10 +634,6 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
     }
 }
 
-// Gap passes (k_gap_finish) take the tasks of at most GAP_MAXLEN steps: one wave walks all tiles of a task.  The few longer
-// ones (rows next to the matrix end, whose ranges are not bounded from the right) stay ordinary own-tiled tasks.
-constexpr int GAP_MAXLEN = 64 * LT;
-
 // ------------------------------------------------------------------ long tasks with tiles of their own
 // A task with >= LT steps is cut into tiles counted from ITS OWN head (the last one partial): every tile lies in one task,
 // so all of them -- head and tail included -- take the uniform path: one contiguous run of the link array, suffix counts,
@@ -658,7 +655,7 @@ __global__ void __launch_bounds__(256) k_own_map(const RoundCounts *__restrict__
     int32_t rest = rlen[lo] - kt * LT;                // steps of the task from this tile on
     int32_t tl = (rest < LT ? rest : LT) - 1;
     // {column of step 0, row, pos[row], tl | tile of a gap task | head}
-    const bool isgap = gap_hi && rlen[lo] <= GAP_MAXLEN;
+    const bool isgap = gap_hi != nullptr;
     rec[tile] = make_int4(td.x - kt * LT, td.z, td.w, (tl << 2) | (isgap ? 2 : 0) | (kt == 0 ? 1 : 0));
     tile_task[tile] = (int32_t)lo;
     if (isgap) {                                       // gap pass: rows (r - 2^tau, hi) of the rectangle are finished together
@@ -824,133 +821,239 @@ __device__ __forceinline__ int32_t gap_right_counts(const int32_t *__restrict__ 
 }
 
 template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n,
-                                                    const int64_t *__restrict__ toffs, const Best<TC, HYP> *__restrict__ part,
-                                                    const Best<TC, HYP> *__restrict__ sub, const int32_t *__restrict__ spv, const uint8_t *__restrict__ spec,
+struct GapCtx {
+    const Best<TC, HYP> *part, *sub; const int32_t *spv; const uint8_t *spec;
+    const int64_t *tilePS, *tilePS2;
+    const int32_t *pos, *next, *fpos, *flast;
+    const TC *W;
+};
+
+// the tiles [ka, kz) of a task (first tile k0, head B, L steps, row r) walked for the 64 rows of the wave: the winners so far
+// (bv, bp, bl, bl2) and the specials the rows count so far (cum, cum2) are carried in and out
+template <typename TC, bool HYP>
+__device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevModel<TC> &M, TC alpha, int64_t ka, int64_t kz, int64_t k0,
+                                         int32_t B, int32_t L, int32_t r, int32_t posr, int32_t rr, int32_t rcmp, bool valid, int lane,
+                                         TC &bv, int32_t &bp, int32_t &bl, int32_t &bl2, int32_t &cum, int32_t &cum2)
+{
+    const int64_t ps0 = C.tilePS[k0], ps20 = HYP ? C.tilePS2[k0] : 0;
+    for (int64_t kb = ka; kb < kz; kb += 64) {
+    const int64_t km = kb + lane < kz ? kb + lane : kz - 1;
+    const int32_t m_base = (int32_t)(C.tilePS[km] - ps0), m_base2 = HYP ? (int32_t)(C.tilePS2[km] - ps20) : 0;
+    const int m_ns = C.spec[km];
+    Best<TC, HYP> m_part; best_clear(m_part);
+    if (m_ns == 0) m_part = C.part[km];
+    const int nb = (int)(kz - kb < 64 ? kz - kb : 64);
+    for (int i = 0; i < nb; i++) {
+        const int64_t k = kb + i;
+        const int32_t base = __shfl(m_base, i), base2 = HYP ? __shfl(m_base2, i) : 0;
+        const int ns = __shfl(m_ns, i);
+        if (ns <= SMAX) {
+            // plain tile: one winner; tile with ns specials: ns + 1 segment winners, a special between two segments
+            Best<TC, HYP> c; best_clear(c);
+            int32_t sv = 0;
+            if (ns == 0) {
+                c.v = shfl64(m_part.v, i); c.p = __shfl(m_part.p, i); c.nn = __shfl(m_part.nn, i);
+                if (HYP) best_set_nl(c, __shfl(best_nl(m_part), i));
+            } else {
+                if (lane <= ns) c = C.sub[k * (SMAX + 1) + lane];
+                if (lane < ns) sv = C.spv[k * (SMAX + 1) + lane];
+            }
+            for (int sg = 0; sg <= ns; sg++) {
+                Best<TC, HYP> d = c;
+                if (ns) { d.v = shfl64(c.v, sg); d.p = __shfl(c.p, sg); d.nn = __shfl(c.nn, sg); if (HYP) best_set_nl(d, __shfl(best_nl(c), sg)); }
+                if (d.p >= 0) {
+                    int32_t lc = d.nn + base + cum, lc2 = HYP ? best_nl(d) + base2 + cum2 : 0;
+                    TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum), (int64_t)(base2 + cum2)));
+                    if (bp < 0 || v < bv) { bv = v; bp = d.p; bl = lc; bl2 = lc2; }
+                }
+                if (sg < ns) {                          // the candidates from here on have this special on their right
+                    const int32_t s1 = __shfl(sv, sg), val = s1 & 0x7fffffff;
+                    if (s1 >= 0) cum += (val >= rcmp);
+                    else cum2 += (valid && val < rr);
+                }
+            }
+            continue;
+        }
+        // too many specials: every lane counts for its own row, entry by entry
+        const int head = k == k0 ? 1 : 0;
+        const int32_t pf = B - (int32_t)(k - k0) * LT;
+        int32_t tlk = L - (int32_t)(k - k0) * LT; tlk = (tlk < LT ? tlk : LT) - 1;
+        // C.pos[pf + 1 - j] and C.W[pf - j] of the tile's columns are fetched lane-strided; the entries come through 64-entry
+        // windows (one coalesced load each) and are handed to all lanes one at a time
+#define CP_SEL5(a_, i_) ((i_) < 64 ? a_[0] : (i_) < 128 ? a_[1] : (i_) < 192 ? a_[2] : (i_) < 256 ? a_[3] : a_[4])
+        int32_t pk[5], pk2[5] = {0, 0, 0, 0, 0}; TC wk[4];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            int32_t e = lane + 64 * j;
+            pk[j] = e <= tlk + 1 ? C.pos[pf + 1 - e] : 0;
+            if (HYP) pk2[j] = e <= tlk + 1 ? C.fpos[pf + 1 - e] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { int32_t e = lane + 64 * j; wk[j] = e <= tlk ? C.W[pf - e] : (TC)0; }
+        int32_t run = 0, run2 = 0;
+        int32_t wb = INT32_MAX, reg = 0, wb2 = INT32_MAX, reg2 = 0;
+        for (int32_t e = 0; e <= tlk; e++) {
+            const int32_t p = pf - e, e1 = e + 1;
+            const int32_t en = __shfl(CP_SEL5(pk, e), e & 63), st = __shfl(CP_SEL5(pk, e1), e1 & 63);      // C.pos[p + 1], C.pos[p]
+            if (!(head && e == 0)) {                    // step over column p (the head element steps over nothing)
+                for (int32_t q = en - 1; q >= st; q--) {
+                    if (q < wb || q - wb > 63) { wb = q - 63; reg = wb + lane >= 0 ? C.next[wb + lane] : 0; }
+                    const int32_t x = __shfl(reg, q - wb);           // (every lane takes part: no short-circuit around a shuffle)
+                    run += (x >= rcmp);
+                }
+                if (HYP) {
+                    const int32_t en2 = __shfl(CP_SEL5(pk2, e), e & 63), st2 = __shfl(CP_SEL5(pk2, e1), e1 & 63);
+                    for (int32_t q = en2 - 1; q >= st2; q--) {
+                        if (q < wb2 || q - wb2 > 63) { wb2 = q - 63; reg2 = wb2 + lane >= 0 ? C.flast[wb2 + lane] : 0; }
+                        const int32_t x = __shfl(reg2, q - wb2);
+                        run2 += (valid && x < rr);
+                    }
+                }
+            }
+            const TC wp = shfl64(e < 64 ? wk[0] : e < 128 ? wk[1] : e < 192 ? wk[2] : wk[3], e & 63);
+            int32_t lc = base + cum + run, lc2 = base2 + cum2 + run2;
+            TC v = cadd(wp, dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - st), (int64_t)lc, (int64_t)lc2));
+            if (bp < 0 || v < bv) { bv = v; bp = p; bl = lc; bl2 = lc2; }
+        }
+#undef CP_SEL5
+        // from here on the row also counts the specials of this tile it passed
+        cum += run - (int32_t)(C.tilePS[k + 1] - C.tilePS[k]);
+        if (HYP) cum2 += run2 - (int32_t)(C.tilePS2[k + 1] - C.tilePS2[k]);
+    }
+    }
+}
+
+// rows of the wave, right parts and anchors of a gap task: shared by the kernels below
+struct GapRows { int32_t rL, hi, rr, rcmp; bool valid, none; };
+__device__ __forceinline__ GapRows gap_rows(int tau, int ck, int32_t r, int b, int64_t n, int lane)
+{
+    GapRows g;
+    g.rL = r - (1 << tau);
+    int64_t hi64 = (int64_t)r + ((int64_t)1 << tau), re = ((((int64_t)r >> b) + 1) << b);
+    if (hi64 > re) hi64 = re;
+    if (hi64 > n + 1) hi64 = n + 1;
+    g.hi = (int32_t)hi64;
+    g.rr = g.rL + 1 + 64 * ck + lane;                       // this lane's row
+    g.none = g.rL + 1 + 64 * ck >= g.hi;                    // (wave-uniform: the chunk lies beyond the gap's rows)
+    g.valid = g.rr < g.hi;
+    g.rcmp = g.valid ? g.rr : INT32_MAX;                    // an invalid lane counts nothing
+    return g;
+}
+
+constexpr int GAPSEG = 64;      // tiles one wave walks; longer tasks are walked by several waves (k_gap_seg) and merged (k_gap_merge)
+
+template <typename TC, bool HYP>
+struct GapSegRec { TC v; int32_t p, l, l2, cum, cum2, _pad; };
+
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCounts *__restrict__ rc, int64_t n,
+                                                    const int64_t *__restrict__ toffs, GapCtx<TC, HYP> C,
                                                     const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ rlen,
-                                                    const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2,
-                                                    const int32_t *__restrict__ pos, const int32_t *__restrict__ next, const int32_t *__restrict__ prev,
-                                                    const int32_t *__restrict__ fpos, const int32_t *__restrict__ flast,
-                                                    const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
-                                                    const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                                    int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin)
+                                                    const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
+                                                    DevModel<TC> M, TC alpha,
+                                                    int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin,
+                                                    int2 *__restrict__ glist)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nwork = (int64_t)rc->nown * nchunk, n1 = n + 1;
     for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
         const int64_t t = w / nchunk;
         const int ck = (int)(w - t * nchunk);
+        const int64_t k0 = toffs[t], k1 = toffs[t + 1];
+        if (k1 - k0 > GAPSEG) {                             // (wave-uniform) a long task: listed for k_gap_seg / k_gap_merge
+            if (ck == 0 && lane == 0) {
+                int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
+                int idx = atomicAdd(&rc->n_glong, 1), slot0 = atomicAdd(&rc->n_gslots, nseg);
+                glist[idx] = make_int2((int)t, slot0);
+            }
+            continue;
+        }
         const int4 td = tdesc[t];                           // {B, anchor + right part of the task's own row, row r, pos[r]}
         const int b = tb[t];
         const int32_t B = td.x, r = td.z, posr = td.w, L = rlen[t];
-        if (L > GAP_MAXLEN) continue;                       // (wave-uniform) an ordinary own-tiled task: k_fix_own
-        const int32_t rL = r - (1 << tau);
-        int64_t hi64 = (int64_t)r + ((int64_t)1 << tau), re = ((((int64_t)r >> b) + 1) << b);
-        if (hi64 > re) hi64 = re;
-        if (hi64 > n + 1) hi64 = n + 1;
-        const int32_t hi = (int32_t)hi64;
-        const int32_t rr = rL + 1 + 64 * ck + lane;         // this lane's row
-        if (rL + 1 + 64 * ck >= hi) continue;               // (wave-uniform: the chunk lies beyond the gap's rows)
-        const bool valid = rr < hi;
-        const int32_t rcmp = valid ? rr : INT32_MAX;        // an invalid lane counts nothing
+        const GapRows g = gap_rows(tau, ck, r, b, n, lane);
+        if (g.none) continue;
         // right parts of the rows and the anchor (counts at (B, rL))
-        const int32_t Rr = gap_right_counts<false>(pos, prev, rL, ck, B, (int32_t)n, lane);
-        const int32_t Rr2 = HYP ? gap_right_counts<true>(lpos, lfirst, rL, ck, B, (int32_t)n, lane) : 0;
-        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)rL);
+        const int32_t Rr = gap_right_counts<false>(C.pos, prev, g.rL, ck, B, (int32_t)n, lane);
+        const int32_t Rr2 = HYP ? gap_right_counts<true>(lpos, lfirst, g.rL, ck, B, (int32_t)n, lane) : 0;
+        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)g.rL);
         const int32_t anchor = nnopt[rwL], anchor2 = HYP ? nlopt[rwL] : 0;
-        // walk the tiles (their records are fetched 64 tiles at a time, one per lane; the winners of a tile with specials one
-        // segment per lane)
-        const int64_t k0 = toffs[t], k1 = toffs[t + 1];
-        const int64_t ps0 = tilePS[k0], ps20 = HYP ? tilePS2[k0] : 0;
-        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0;
-        int32_t cum = 0, cum2 = 0;
-        for (int64_t kb = k0; kb < k1; kb += 64) {
-        const int64_t km = kb + lane < k1 ? kb + lane : k1 - 1;
-        const int32_t m_base = (int32_t)(tilePS[km] - ps0), m_base2 = HYP ? (int32_t)(tilePS2[km] - ps20) : 0;
-        const int m_ns = spec[km];
-        Best<TC, HYP> m_part; best_clear(m_part);
-        if (m_ns == 0) m_part = part[km];
-        const int nb = (int)(k1 - kb < 64 ? k1 - kb : 64);
-        for (int i = 0; i < nb; i++) {
-            const int64_t k = kb + i;
-            const int32_t base = __shfl(m_base, i), base2 = HYP ? __shfl(m_base2, i) : 0;
-            const int ns = __shfl(m_ns, i);
-            if (ns <= SMAX) {
-                // plain tile: one winner; tile with ns specials: ns + 1 segment winners, a special between two segments
-                Best<TC, HYP> c; best_clear(c);
-                int32_t sv = 0;
-                if (ns == 0) {
-                    c.v = shfl64(m_part.v, i); c.p = __shfl(m_part.p, i); c.nn = __shfl(m_part.nn, i);
-                    if (HYP) best_set_nl(c, __shfl(best_nl(m_part), i));
-                } else {
-                    if (lane <= ns) c = sub[k * (SMAX + 1) + lane];
-                    if (lane < ns) sv = spv[k * (SMAX + 1) + lane];
-                }
-                for (int sg = 0; sg <= ns; sg++) {
-                    Best<TC, HYP> d = c;
-                    if (ns) { d.v = shfl64(c.v, sg); d.p = __shfl(c.p, sg); d.nn = __shfl(c.nn, sg); if (HYP) best_set_nl(d, __shfl(best_nl(c), sg)); }
-                    if (d.p >= 0) {
-                        int32_t lc = d.nn + base + cum, lc2 = HYP ? best_nl(d) + base2 + cum2 : 0;
-                        TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum), (int64_t)(base2 + cum2)));
-                        if (bp < 0 || v < bv) { bv = v; bp = d.p; bl = lc; bl2 = lc2; }
-                    }
-                    if (sg < ns) {                          // the candidates from here on have this special on their right
-                        const int32_t s1 = __shfl(sv, sg), val = s1 & 0x7fffffff;
-                        if (s1 >= 0) cum += (val >= rcmp);
-                        else cum2 += (valid && val < rr);
-                    }
-                }
-                continue;
-            }
-            // too many specials: every lane counts for its own row, entry by entry
-            const int head = k == k0 ? 1 : 0;
-            const int32_t pf = B - (int32_t)(k - k0) * LT;
-            int32_t tlk = L - (int32_t)(k - k0) * LT; tlk = (tlk < LT ? tlk : LT) - 1;
-            // pos[pf + 1 - j] and W[pf - j] of the tile's columns are fetched lane-strided; the entries come through 64-entry
-            // windows (one coalesced load each) and are handed to all lanes one at a time
-#define CP_SEL5(a_, i_) ((i_) < 64 ? a_[0] : (i_) < 128 ? a_[1] : (i_) < 192 ? a_[2] : (i_) < 256 ? a_[3] : a_[4])
-            int32_t pk[5], pk2[5] = {0, 0, 0, 0, 0}; TC wk[4];
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                int32_t e = lane + 64 * j;
-                pk[j] = e <= tlk + 1 ? pos[pf + 1 - e] : 0;
-                if (HYP) pk2[j] = e <= tlk + 1 ? fpos[pf + 1 - e] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { int32_t e = lane + 64 * j; wk[j] = e <= tlk ? W[pf - e] : (TC)0; }
-            int32_t run = 0, run2 = 0;
-            int32_t wb = INT32_MAX, reg = 0, wb2 = INT32_MAX, reg2 = 0;
-            for (int32_t e = 0; e <= tlk; e++) {
-                const int32_t p = pf - e, e1 = e + 1;
-                const int32_t en = __shfl(CP_SEL5(pk, e), e & 63), st = __shfl(CP_SEL5(pk, e1), e1 & 63);      // pos[p + 1], pos[p]
-                if (!(head && e == 0)) {                    // step over column p (the head element steps over nothing)
-                    for (int32_t q = en - 1; q >= st; q--) {
-                        if (q < wb || q - wb > 63) { wb = q - 63; reg = wb + lane >= 0 ? next[wb + lane] : 0; }
-                        const int32_t x = __shfl(reg, q - wb);           // (every lane takes part: no short-circuit around a shuffle)
-                        run += (x >= rcmp);
-                    }
-                    if (HYP) {
-                        const int32_t en2 = __shfl(CP_SEL5(pk2, e), e & 63), st2 = __shfl(CP_SEL5(pk2, e1), e1 & 63);
-                        for (int32_t q = en2 - 1; q >= st2; q--) {
-                            if (q < wb2 || q - wb2 > 63) { wb2 = q - 63; reg2 = wb2 + lane >= 0 ? flast[wb2 + lane] : 0; }
-                            const int32_t x = __shfl(reg2, q - wb2);
-                            run2 += (valid && x < rr);
-                        }
-                    }
-                }
-                const TC wp = shfl64(e < 64 ? wk[0] : e < 128 ? wk[1] : e < 192 ? wk[2] : wk[3], e & 63);
-                int32_t lc = base + cum + run, lc2 = base2 + cum2 + run2;
-                TC v = cadd(wp, dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - st), (int64_t)lc, (int64_t)lc2));
-                if (bp < 0 || v < bv) { bv = v; bp = p; bl = lc; bl2 = lc2; }
-            }
-#undef CP_SEL5
-            // from here on the row also counts the specials of this tile it passed
-            cum += run - (int32_t)(tilePS[k + 1] - tilePS[k]);
-            if (HYP) cum2 += run2 - (int32_t)(tilePS2[k + 1] - tilePS2[k]);
+        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
+        gap_walk<TC, HYP>(C, M, alpha, k0, k1, k0, B, L, r, posr, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
+        if (g.valid) {
+            int64_t rw = (int64_t)b * n1 + PR((int64_t)g.rr);
+            opt[rw] = bp; nnopt[rw] = anchor + Rr + bl;
+            if (HYP) nlopt[rw] = anchor2 + Rr2 + bl2;
+            fin[rw] = 1;
         }
+    }
+}
+
+// long gap tasks, phase 1: one wave per (listed task, GAPSEG tiles, 64 rows) walks its tiles as if nothing lay in front of them
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n, const int64_t *__restrict__ toffs,
+                                                 GapCtx<TC, HYP> C, const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
+                                                 const int32_t *__restrict__ rlen, DevModel<TC> M, TC alpha, const int2 *__restrict__ glist,
+                                                 GapSegRec<TC, HYP> *__restrict__ gseg)
+{
+    const int lane = threadIdx.x & 63;
+    const int nlist = rc->n_glong;
+    for (int i = blockIdx.y; i < nlist; i += gridDim.y) {
+        const int2 le = glist[i];
+        const int64_t t = le.x, k0 = toffs[t], k1 = toffs[t + 1];
+        const int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
+        const int4 td = tdesc[t];
+        const int b = tb[t];
+        const int32_t L = rlen[t];
+        for (int sw = blockIdx.x * 4 + (threadIdx.x >> 6); sw < nseg * nchunk; sw += gridDim.x * 4) {
+            const int sg = sw / nchunk, ck = sw - sg * nchunk;
+            const GapRows g = gap_rows(tau, ck, td.z, b, n, lane);
+            if (g.none) continue;
+            TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
+            const int64_t ka = k0 + (int64_t)sg * GAPSEG, kz = ka + GAPSEG < k1 ? ka + GAPSEG : k1;
+            gap_walk<TC, HYP>(C, M, alpha, ka, kz, k0, td.x, L, td.z, td.w, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
+            GapSegRec<TC, HYP> rec; rec.v = bv; rec.p = bp; rec.l = bl; rec.l2 = bl2; rec.cum = cum; rec.cum2 = cum2; rec._pad = 0;
+            gseg[((int64_t)(le.y + sg) * nchunk + ck) * 64 + lane] = rec;
         }
-        if (valid) {
-            int64_t rw = (int64_t)b * n1 + PR((int64_t)rr);
+    }
+}
+
+// phase 2: one wave per (listed task, 64 rows) merges the segment winners in walking order, adding the specials of the
+// segments in front
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_gap_merge(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n, const int64_t *__restrict__ toffs,
+                                                   const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
+                                                   const int32_t *__restrict__ pos, const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos,
+                                                   const int32_t *__restrict__ lfirst, DevModel<TC> M, const int2 *__restrict__ glist,
+                                                   const GapSegRec<TC, HYP> *__restrict__ gseg,
+                                                   int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nwork = (int64_t)rc->n_glong * nchunk, n1 = n + 1;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+        const int i = (int)(w / nchunk), ck = (int)(w - (int64_t)i * nchunk);
+        const int2 le = glist[i];
+        const int64_t t = le.x, k0 = toffs[t], k1 = toffs[t + 1];
+        const int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
+        const int4 td = tdesc[t];
+        const int b = tb[t];
+        const GapRows g = gap_rows(tau, ck, td.z, b, n, lane);
+        if (g.none) continue;
+        const int32_t Rr = gap_right_counts<false>(pos, prev, g.rL, ck, td.x, (int32_t)n, lane);
+        const int32_t Rr2 = HYP ? gap_right_counts<true>(lpos, lfirst, g.rL, ck, td.x, (int32_t)n, lane) : 0;
+        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)g.rL);
+        const int32_t anchor = nnopt[rwL], anchor2 = HYP ? nlopt[rwL] : 0;
+        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
+        for (int sg = 0; sg < nseg; sg++) {
+            const GapSegRec<TC, HYP> rec = gseg[((int64_t)(le.y + sg) * nchunk + ck) * 64 + lane];
+            if (rec.p >= 0) {
+                TC v = cadd(rec.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)cum, (int64_t)cum2));
+                if (bp < 0 || v < bv) { bv = v; bp = rec.p; bl = rec.l + cum; bl2 = rec.l2 + cum2; }
+            }
+            cum += rec.cum; cum2 += rec.cum2;
+        }
+        if (g.valid) {
+            int64_t rw = (int64_t)b * n1 + PR((int64_t)g.rr);
             opt[rw] = bp; nnopt[rw] = anchor + Rr + bl;
             if (HYP) nlopt[rw] = anchor2 + Rr2 + bl2;
             fin[rw] = 1;
@@ -980,14 +1083,14 @@ __global__ void __launch_bounds__(256) k_fix_own_lane(RoundCounts *__restrict__ 
                                                       const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ tS0l,
                                                       const int64_t *__restrict__ tilePS, const int64_t *__restrict__ tilePS2, DevModel<TC> M,
                                                       int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, int64_t n1,
-                                                      int32_t *__restrict__ wide_list, const int32_t *__restrict__ rlen, int gap_round)
+                                                      int32_t *__restrict__ wide_list)
 {
     const int64_t ntask = rc->nown;
     int lane = threadIdx.x & 63;
     for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < ntask; t0 += (int64_t)gridDim.x * blockDim.x) {      // wave-uniform
         int64_t t = t0 + threadIdx.x;
         int64_t k0 = 0, k1 = 0;
-        if (t < ntask && !(gap_round && rlen[t] <= GAP_MAXLEN)) { k0 = toffs[t]; k1 = toffs[t + 1]; }      // (gap tasks: k_gap_finish)
+        if (t < ntask) { k0 = toffs[t]; k1 = toffs[t + 1]; }
         int64_t nt = k1 - k0;
         bool wide = nt > FIX_SERIAL;
         unsigned long long mw = __ballot(wide);
@@ -1459,6 +1562,8 @@ struct LayerWork {
     DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2, o_wide, o_hi;
     DBuf<Best<TC, true>> o_sub;                         // gap passes: segment winners of the tiles with specials, [tile][SMAX + 1]
     DBuf<int32_t> o_spv;                                // ... and the specials between them
+    DBuf<int2> g_list;                                  // gap tasks of more than GAPSEG tiles: {task, first segment slot}
+    DBuf<char> g_seg;                                   // their segment records (GapSegRec)
     DBuf<int32_t> last_s0;                              // anchors of the last row's round-A tasks ([b], [32 + b])
     DBuf<uint8_t> o_spec, fin;                          // gap passes: flagged tiles; rows already final (per plane slot)
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
@@ -1691,23 +1796,38 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 if (hyp) exclusive_scan_i32_devn(Wk.o_tileS2.p, Wk.o_tilePS2.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
             }
             if (gap) {
-                // every row of the gaps gets its winner: one wave per (task, 64 rows)
+                // every row of the gaps gets its winner: one wave per (task, 64 rows); tasks of more than GAPSEG tiles in two steps
                 ProfScope ps(PROF_GAP, s, 24.0 * (double)P.NT);
                 const int nchunk = (int)std::max<int64_t>(1, ((int64_t)2 << R.tau) / 64);
+                const size_t ncap = Wk.o_rec.n / GAPSEG + 2;
+                Wk.g_list.ensure(ncap);
+                Wk.g_seg.ensure((2 * ncap) * (size_t)nchunk * 64 * sizeof(GapSegRec<TC, true>));
                 unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * nchunk, 4), 16384);
-#define GF_ARGS R.tau, nchunk, rc, n, Wk.o_toffs.p
-#define GF_TAIL Wk.o_spec.p, Wk.o_tdesc.p, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->prev.p,                                \
-                hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr, hyp ? A->lpos32.p : (const int32_t *)nullptr,          \
-                hyp ? A->lfirst.p : (const int32_t *)nullptr, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p
-                if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true>), dim3(gg), dim3(256), 0, s, GF_ARGS, Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, GF_TAIL);
-                else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false>), dim3(gg), dim3(256), 0, s, GF_ARGS,
-                                            reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p),
-                                            Wk.o_spv.p, GF_TAIL);
-#undef GF_ARGS
-#undef GF_TAIL
-            }
-            {
-                // (gap rounds: only the tasks too long for a gap pass are merged here)
+                unsigned gy = (unsigned)std::min<int64_t>((int64_t)ncap, 2048);
+                unsigned gm = (unsigned)std::min<int64_t>(cdiv((int64_t)ncap * nchunk, 4), 4096);
+                if (hyp) {
+                    GapCtx<TC, true> C{Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, Wk.o_spec.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->fpos32.p, A->flast.p, W};
+                    auto *gs = reinterpret_cast<GapSegRec<TC, true> *>(Wk.g_seg.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(32, gy), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, M, alpha, Wk.g_list.p, gs);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, true>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       A->pos32.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p);
+                } else {
+                    GapCtx<TC, false> C{reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p), Wk.o_spv.p,
+                                        Wk.o_spec.p, Wk.o_tilePS.p, nullptr, A->pos32.p, A->next.p, nullptr, nullptr, W};
+                    auto *gs = reinterpret_cast<GapSegRec<TC, false> *>(Wk.g_seg.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
+                                       Wk.fin.p, Wk.g_list.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(32, gy), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, M, alpha, Wk.g_list.p, gs);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, false>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       A->pos32.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p,
+                                       (int32_t *)nullptr, Wk.fin.p);
+                }
+            } else {
                 ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
                 // one lane per task: single tiles are final already, short tasks are merged on the spot, the rest is listed
                 bool wide = P.NT > 64 * (int64_t)P.nown;         // on average more than 64 tiles per task: one block per listed task
@@ -1716,7 +1836,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
 #define FO_TAIL Wk.o_tdesc.p, Wk.o_tb.p
                 if (hyp) {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own_lane<TC, true>), dim3(lgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL, Wk.o_tS0l.p,
-                                       Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p, Wk.o_rlen.p, gap ? 1 : 0);
+                                       Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p);
                     if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 4>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p, FO_TAIL,
                                                  Wk.o_tS0l.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, M, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, n + 1, Wk.o_wide.p);
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, true, 1>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, Wk.o_part.p,
@@ -1724,7 +1844,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 } else {
                     const Best<TC, false> *pp = reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own_lane<TC, false>), dim3(lgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL, (const int32_t *)nullptr,
-                                       Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p, Wk.o_rlen.p, gap ? 1 : 0);
+                                       Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p);
                     if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 4>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
                                                  (const int32_t *)nullptr, Wk.o_tilePS.p, (const int64_t *)nullptr, M, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, n + 1, Wk.o_wide.p);
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fix_own<TC, false, 1>), dim3(wgrid), dim3(256), 0, s, FO_ARGS, pp, FO_TAIL,
