@@ -14,7 +14,7 @@ ProfSlot g_prof[PROF_NSLOTS] = {
     {"dp_lpass", 0, 0, 0}, {"dp_open_segments", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
     {"scan", 0, 0, 0}, {"dp_tile_carry", 0, 0, 0}, {"dp_span_fix", 0, 0, 0}, {"dp_combine", 0, 0, 0},
     {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
-    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}};
+    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}, {"dp_lpass_gap", 0, 0, 0}};
 bool g_prof_on = false;
 int g_prof_only = -1;
 std::vector<ProfPending> g_prof_pending;
@@ -323,13 +323,14 @@ __global__ void k_count_first_last(const int32_t *__restrict__ rfirst, const int
 __global__ void k_scatter_first_last(const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
                                      const int64_t *__restrict__ fpos, const int64_t *__restrict__ lpos,
                                      int32_t *__restrict__ cf, int32_t *__restrict__ cl,
-                                     int32_t *__restrict__ flast, int32_t *__restrict__ lfirst, int64_t m)
+                                     int32_t *__restrict__ flast, int32_t *__restrict__ lfirst, int32_t *__restrict__ ffirst, int64_t m)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m || rfirst[r] < 0) return;
     // order inside a bucket is irrelevant: only counts of entries below/above a threshold are used
     int a = atomicAdd(&cf[rfirst[r]], 1);
     flast[fpos[rfirst[r]] + a] = rlast[r];
+    ffirst[fpos[rfirst[r]] + a] = rfirst[r];
     int b = atomicAdd(&cl[rlast[r]], 1);
     lfirst[lpos[rlast[r]] + b] = rfirst[r];
 }
@@ -353,10 +354,11 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipStreamSynchronize(s));
     A->nrows_nonempty = tot;
     A->flast.alloc((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.alloc((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
+    A->ffirst.alloc((size_t)(tot > 0 ? tot : 1) + 8);
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,
-                                  A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, m);
+                                  A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, A->ffirst.p, m);
     A->fpos32.alloc((size_t)n + 1); A->lpos32.alloc((size_t)n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->fpos.p, A->fpos32.p, n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->lpos.p, A->lpos32.p, n + 1);
@@ -370,7 +372,7 @@ void drop_cache(cp_csr_s *A)
     A->have_links = false; A->have_self = false;
     A->col.release(); A->prev.release(); A->next.release(); A->rfirst.release(); A->rlast.release();
     A->pos32.release(); A->fpos32.release(); A->lpos32.release();
-    A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release();
+    A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release(); A->ffirst.release();
 }
 
 }  // namespace cpk

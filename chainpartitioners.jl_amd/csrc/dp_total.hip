@@ -556,13 +556,15 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // a block is counted); per block: four ballots, a per-lane popcount prefix, and one gather per step whose column starts
 // inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
 // DET (gap passes, see k_gap_finish): the entries of the run with a value strictly between sp_lo and sp_hi ("specials") are
-// appended to the wave's list: s_es[i] = first step e whose candidate has the entry's column on its right (steps >= e count
-// it), s_v[i] = the value, tagged with `kind` in bit 31.  `ns` counts them (wave-uniform; only the first SMAX are stored).
+// appended to the wave's list by the lanes that hold them (LDS counter s_cnt): s_es[i] = first step e whose candidate has the
+// entry's column on its right (steps >= e count it) = p_first - column, s_v[i] = the value, tagged with `kind` in bit 31.
+// ecol: the column of every entry of arr.  Only the first SMAX specials are stored; s_cnt keeps counting.
 constexpr int SMAX = 31;
 template <bool GE, bool DET = false>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
                                                 int32_t thr, int lane, int32_t acc[4], int32_t sk[4], int head = 0, int32_t sp_lo = 0, int32_t sp_hi = 0,
-                                                int32_t *s_es = nullptr, int32_t *s_v = nullptr, int *ns_ = nullptr, int kind = 0)
+                                                int32_t *s_es = nullptr, int32_t *s_v = nullptr, int32_t *s_cnt = nullptr, int kind = 0,
+                                                const int32_t *__restrict__ ecol = nullptr)
 {
     const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
 #pragma unroll
@@ -591,23 +593,19 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
             else    { m0 = __ballot(pb < Q_hi && v.x < thr); m1 = __ballot(pb + 1 < Q_hi && v.y < thr);
                       m2 = __ballot(pb + 2 < Q_hi && v.z < thr); m3 = __ballot(pb + 3 < Q_hi && v.w < thr); }
             if (DET) {
-                bool s0 = pb >= Q_lo && pb < Q_hi && v.x > sp_lo && v.x < sp_hi, s1 = pb + 1 >= Q_lo && pb + 1 < Q_hi && v.y > sp_lo && v.y < sp_hi;
-                bool s2 = pb + 2 >= Q_lo && pb + 2 < Q_hi && v.z > sp_lo && v.z < sp_hi, s3 = pb + 3 >= Q_lo && pb + 3 < Q_hi && v.w > sp_lo && v.w < sp_hi;
-                if (__ballot(s0 || s1 || s2 || s3)) {                 // wave-uniform, rare
+                const uint32_t span = (uint32_t)(sp_hi - sp_lo - 1);           // v in (sp_lo, sp_hi)  <=>  (uint)(v - sp_lo - 1) < span
+                bool s0 = pb >= Q_lo && pb < Q_hi && (uint32_t)(v.x - sp_lo - 1) < span, s1 = pb + 1 >= Q_lo && pb + 1 < Q_hi && (uint32_t)(v.y - sp_lo - 1) < span;
+                bool s2 = pb + 2 >= Q_lo && pb + 2 < Q_hi && (uint32_t)(v.z - sp_lo - 1) < span, s3 = pb + 3 >= Q_lo && pb + 3 < Q_hi && (uint32_t)(v.w - sp_lo - 1) < span;
+                if (s0 || s1 || s2 || s3) {                           // rare; only the lanes holding a special work here
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        unsigned long long m = __ballot(j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3);
-                        while (m) {
-                            int l = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            int32_t q = xc + 4 * l + j;               // position of the special entry (uniform)
-                            int32_t val = __shfl(j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w, l);
-                            int cnt = 0;                              // steps whose column starts behind q: the entry's column is step `cnt`
-#pragma unroll
-                            for (int k = 0; k < 4; k++) cnt += __popcll(__ballot(lane + 64 * k <= tl && sk[k] > q));
-                            int ns = *ns_;
-                            if (ns < SMAX && lane == 0) { s_es[ns] = cnt; s_v[ns] = (int32_t)(((uint32_t)val & 0x7fffffffu) | ((uint32_t)kind << 31)); }
-                            *ns_ = ns + 1;
+                        if (j == 0 ? s0 : j == 1 ? s1 : j == 2 ? s2 : s3) {
+                            int32_t val = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+                            int slot = atomicAdd(s_cnt, 1);
+                            if (slot <= SMAX - 1) {
+                                s_es[slot] = p_first - ecol[pb + j];
+                                s_v[slot] = (int32_t)(((uint32_t)val & 0x7fffffffu) | ((uint32_t)kind << 31));
+                            }
                         }
                     }
                 }
@@ -674,7 +672,8 @@ __global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *_
                                                    int32_t *__restrict__ a_tileS, int32_t *__restrict__ a_tileS2, const int4 *__restrict__ a_rec,
                                                    const TC *__restrict__ W, DevModel<TC> M, TC alpha, Best<TC, HYP> *__restrict__ part,
                                                    int tau, const int32_t *__restrict__ gap_hi, uint8_t *__restrict__ spec, int force_spec,
-                                                   Best<TC, HYP> *__restrict__ sub, int32_t *__restrict__ spv)
+                                                   Best<TC, HYP> *__restrict__ sub, int32_t *__restrict__ spv,
+                                                   const int32_t *__restrict__ a_col, const int32_t *__restrict__ a_ffirst)
 {
     // GAP (rounds tau <= gap_tau, see k_gap_finish): the tile is evaluated for ALL rows r' of (r - 2^tau, hi) at once: the counts
     // taken here are those of the entries every such row counts (next >= hi - 1; last <= r - 2^tau), the candidates are valued
@@ -692,12 +691,18 @@ __global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *_
     int32_t tl = rec.w >> 2;
     int32_t acc[4], acc2[4] = {0, 0, 0, 0}, sk[4], sk2[4];
     __shared__ int32_t s_es_all[4][2][SMAX + 1], s_v_all[4][2][SMAX + 1];      // the wave's specials: as found / sorted by step
+    __shared__ int32_t s_cnt_all[4];
     int32_t(*s_es)[SMAX + 1] = s_es_all[threadIdx.x >> 6], (*s_v)[SMAX + 1] = s_v_all[threadIdx.x >> 6];
     int ns = 0;
     if (GAP && (rec.w & 2)) {
+        int32_t *s_cnt = &s_cnt_all[threadIdx.x >> 6];
+        if (lane == 0) *s_cnt = 0;
+        __threadfence_block();
         int32_t rL = rec.y - (1 << tau), hi1 = gap_hi[tile] - 1;
-        interior_stream<true, true>(a_next, a_pos, rec.x, tl, hi1, lane, acc, sk, head, rL, hi1, s_es[0], s_v[0], &ns, 0);
-        if (HYP) interior_stream<false, true>(a_flast, a_fpos, rec.x, tl, rL + 1, lane, acc2, sk2, head, rL, hi1, s_es[0], s_v[0], &ns, 1);
+        interior_stream<true, true>(a_next, a_pos, rec.x, tl, hi1, lane, acc, sk, head, rL, hi1, s_es[0], s_v[0], s_cnt, 0, a_col);
+        if (HYP) interior_stream<false, true>(a_flast, a_fpos, rec.x, tl, rL + 1, lane, acc2, sk2, head, rL, hi1, s_es[0], s_v[0], s_cnt, 1, a_ffirst);
+        __threadfence_block();
+        ns = *s_cnt;
         if (force_spec) ns = SMAX + 1;
     } else {
         interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk, head);
@@ -940,7 +945,7 @@ __device__ __forceinline__ GapRows gap_rows(int tau, int ck, int32_t r, int b, i
     return g;
 }
 
-constexpr int GAPSEG = 64;      // tiles one wave walks; longer tasks are walked by several waves (k_gap_seg) and merged (k_gap_merge)
+constexpr int GAPSEG = 16;      // tiles one wave walks; longer tasks are walked by several waves (k_gap_seg) and merged (k_gap_merge)
 
 template <typename TC, bool HYP>
 struct GapSegRec { TC v; int32_t p, l, l2, cum, cum2, _pad; };
@@ -952,7 +957,7 @@ __global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCo
                                                     const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
                                                     DevModel<TC> M, TC alpha,
                                                     int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin,
-                                                    int2 *__restrict__ glist)
+                                                    int2 *__restrict__ glist, int2 *__restrict__ gslot)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nwork = (int64_t)rc->nown * nchunk, n1 = n + 1;
@@ -965,6 +970,7 @@ __global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCo
                 int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
                 int idx = atomicAdd(&rc->n_glong, 1), slot0 = atomicAdd(&rc->n_gslots, nseg);
                 glist[idx] = make_int2((int)t, slot0);
+                for (int j = 0; j < nseg; j++) gslot[slot0 + j] = make_int2((int)t, j);       // slot -> (task, segment) for k_gap_seg
             }
             continue;
         }
@@ -989,32 +995,30 @@ __global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCo
     }
 }
 
-// long gap tasks, phase 1: one wave per (listed task, GAPSEG tiles, 64 rows) walks its tiles as if nothing lay in front of them
+// long gap tasks, phase 1: one wave per (segment slot = GAPSEG tiles of a listed task, 64 rows) walks its tiles as if nothing lay
+// in front of them
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n, const int64_t *__restrict__ toffs,
                                                  GapCtx<TC, HYP> C, const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
-                                                 const int32_t *__restrict__ rlen, DevModel<TC> M, TC alpha, const int2 *__restrict__ glist,
+                                                 const int32_t *__restrict__ rlen, DevModel<TC> M, TC alpha, const int2 *__restrict__ gslot,
                                                  GapSegRec<TC, HYP> *__restrict__ gseg)
 {
     const int lane = threadIdx.x & 63;
-    const int nlist = rc->n_glong;
-    for (int i = blockIdx.y; i < nlist; i += gridDim.y) {
-        const int2 le = glist[i];
-        const int64_t t = le.x, k0 = toffs[t], k1 = toffs[t + 1];
-        const int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
+    const int64_t nwork = (int64_t)rc->n_gslots * nchunk;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+        const int64_t slot = w / nchunk;
+        const int ck = (int)(w - slot * nchunk);
+        const int2 se = gslot[slot];
+        const int64_t t = se.x, k0 = toffs[t], k1 = toffs[t + 1];
+        const int sg = se.y;
         const int4 td = tdesc[t];
-        const int b = tb[t];
-        const int32_t L = rlen[t];
-        for (int sw = blockIdx.x * 4 + (threadIdx.x >> 6); sw < nseg * nchunk; sw += gridDim.x * 4) {
-            const int sg = sw / nchunk, ck = sw - sg * nchunk;
-            const GapRows g = gap_rows(tau, ck, td.z, b, n, lane);
-            if (g.none) continue;
-            TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
-            const int64_t ka = k0 + (int64_t)sg * GAPSEG, kz = ka + GAPSEG < k1 ? ka + GAPSEG : k1;
-            gap_walk<TC, HYP>(C, M, alpha, ka, kz, k0, td.x, L, td.z, td.w, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
-            GapSegRec<TC, HYP> rec; rec.v = bv; rec.p = bp; rec.l = bl; rec.l2 = bl2; rec.cum = cum; rec.cum2 = cum2; rec._pad = 0;
-            gseg[((int64_t)(le.y + sg) * nchunk + ck) * 64 + lane] = rec;
-        }
+        const GapRows g = gap_rows(tau, ck, td.z, tb[t], n, lane);
+        if (g.none) continue;
+        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
+        const int64_t ka = k0 + (int64_t)sg * GAPSEG, kz = ka + GAPSEG < k1 ? ka + GAPSEG : k1;
+        gap_walk<TC, HYP>(C, M, alpha, ka, kz, k0, td.x, rlen[t], td.z, td.w, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
+        GapSegRec<TC, HYP> rec; rec.v = bv; rec.p = bp; rec.l = bl; rec.l2 = bl2; rec.cum = cum; rec.cum2 = cum2; rec._pad = 0;
+        gseg[(slot * nchunk + ck) * 64 + lane] = rec;
     }
 }
 
@@ -1562,6 +1566,7 @@ struct LayerWork {
     DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2, o_wide, o_hi;
     DBuf<Best<TC, true>> o_sub;                         // gap passes: segment winners of the tiles with specials, [tile][SMAX + 1]
     DBuf<int32_t> o_spv;                                // ... and the specials between them
+    DBuf<int2> g_slot;                                  // segment slot -> {task, segment}
     DBuf<int2> g_list;                                  // gap tasks of more than GAPSEG tiles: {task, first segment slot}
     DBuf<char> g_seg;                                   // their segment records (GapSegRec)
     DBuf<int32_t> last_s0;                              // anchors of the last row's round-A tasks ([b], [32 + b])
@@ -1700,7 +1705,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     memset(used.data(), 0, sizeof(RoundCounts) * (size_t)NR);
     struct Patch { size_t idx; int rd; int kind; };
     std::vector<Patch> patches;                          // profile records whose algorithmic bytes depend on the true counts
-    auto note = [&](int rd, int kind) { if (prof_active(kind == 0 ? PROF_OWN : PROF_EXPAND)) patches.push_back({g_prof_pending.size() - 1, rd, kind}); };
+    auto note = [&](int rd, int kind, int slot) { if (prof_active(slot)) patches.push_back({g_prof_pending.size() - 1, rd, kind}); };
     auto grow = [](int64_t v) { return v + (v >> 2) + 1024; };     // head room over the prediction
 
     for (int rd = 0; rd <= nbits; rd++) {
@@ -1774,21 +1779,21 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(gNT, 256)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p,
                                Wk.o_tb.p, gap ? Wk.o_hi.p : (int32_t *)nullptr, R.tau, n);
             {
-                ProfScope ps(PROF_OWN, s, (double)P.own_steps * step_bytes);      // same bytes per step as dp_lpass
+                ProfScope ps(gap ? PROF_GAPSTREAM : PROF_OWN, s, (double)P.own_steps * step_bytes);      // same bytes per step as dp_lpass
 #define LO_ARGS R.isA, rc, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr, hyp ? A->flast.p : (const int32_t *)nullptr,            \
                 Wk.o_tileS.p, Wk.o_tileS2.p, Wk.o_rec.p, W, M, alpha
 #define LO_TAIL R.tau, Wk.o_hi.p, Wk.o_spec.p, (int)((g_opt_dbg & 512) != 0)
                 Best<TC, false> *sb0 = reinterpret_cast<Best<TC, false> *>(Wk.o_sub.p);
                 unsigned og = (unsigned)cdiv(gNT, 4);
                 Best<TC, false> *pp0 = reinterpret_cast<Best<TC, false> *>(Wk.o_part.p);
-                if (hyp) { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, true>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p);
-                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, false>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p); }
-                else     { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, true>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p);
-                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, false>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p); }
+                if (hyp) { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, true>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p, A->col.p, A->ffirst.p);
+                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, true, false>), dim3(og), dim3(256), 0, s, LO_ARGS, Wk.o_part.p, LO_TAIL, Wk.o_sub.p, Wk.o_spv.p, A->col.p, A->ffirst.p); }
+                else     { if (gap) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, true>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p, A->col.p, (const int32_t *)nullptr);
+                           else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpass_own<TC, false, false>), dim3(og), dim3(256), 0, s, LO_ARGS, pp0, LO_TAIL, sb0, Wk.o_spv.p, A->col.p, (const int32_t *)nullptr); }
 #undef LO_TAIL
 #undef LO_ARGS
             }
-            note(rd, 0);
+            note(rd, 0, gap ? PROF_GAPSTREAM : PROF_OWN);
             {
                 ProfScope ps(PROF_CARRY, s, 12.0 * (double)P.NT);
                 const int32_t *ntp = reinterpret_cast<const int32_t *>(&rc->NT);       // (NT < 2^31: the low word)
@@ -1800,18 +1805,18 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 ProfScope ps(PROF_GAP, s, 24.0 * (double)P.NT);
                 const int nchunk = (int)std::max<int64_t>(1, ((int64_t)2 << R.tau) / 64);
                 const size_t ncap = Wk.o_rec.n / GAPSEG + 2;
-                Wk.g_list.ensure(ncap);
+                Wk.g_list.ensure(ncap); Wk.g_slot.ensure(2 * ncap);
                 Wk.g_seg.ensure((2 * ncap) * (size_t)nchunk * 64 * sizeof(GapSegRec<TC, true>));
                 unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * nchunk, 4), 16384);
-                unsigned gy = (unsigned)std::min<int64_t>((int64_t)ncap, 2048);
+                unsigned gs_grid = (unsigned)std::min<int64_t>(cdiv((int64_t)(2 * ncap) * nchunk, 4), 8192);
                 unsigned gm = (unsigned)std::min<int64_t>(cdiv((int64_t)ncap * nchunk, 4), 4096);
                 if (hyp) {
                     GapCtx<TC, true> C{Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, Wk.o_spec.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->fpos32.p, A->flast.p, W};
                     auto *gs = reinterpret_cast<GapSegRec<TC, true> *>(Wk.g_seg.p);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(32, gy), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, M, alpha, Wk.g_list.p, gs);
+                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, true>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
                                        A->pos32.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p);
                 } else {
@@ -1820,9 +1825,9 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     auto *gs = reinterpret_cast<GapSegRec<TC, false> *>(Wk.g_seg.p);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                                       Wk.fin.p, Wk.g_list.p);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(32, gy), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, M, alpha, Wk.g_list.p, gs);
+                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, false>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
                                        A->pos32.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p,
                                        (int32_t *)nullptr, Wk.fin.p);
@@ -1830,7 +1835,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             } else {
                 ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
                 // one lane per task: single tiles are final already, short tasks are merged on the spot, the rest is listed
-                bool wide = P.NT > 64 * (int64_t)P.nown;         // on average more than 64 tiles per task: one block per listed task
+                const bool wide = true;                          // one block per listed task (the longest task sets the pace)
                 unsigned lgrid = (unsigned)std::min<int64_t>(cdiv(gown, 256), 4096), wgrid = (unsigned)std::min<int64_t>(wide ? gown : cdiv(gown, 4), 8192);
 #define FO_ARGS rc, Wk.o_toffs.p
 #define FO_TAIL Wk.o_tdesc.p, Wk.o_tb.p
@@ -1882,7 +1887,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                                         reinterpret_cast<Best<TC, false> *>(Wk.partR.p), reinterpret_cast<Best<TC, false> *>(Wk.partL.p));
 #undef LP_ARGS
         }
-        note(rd, 1);
+        note(rd, 1, PROF_EXPAND);
         {
             ProfScope ps(PROF_CARRY, s, 12.0 * (double)cdiv(P.T, LT));
             exclusive_scan_i32_devn(Wk.tileS.p, Wk.tilePS.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scratch, s);
