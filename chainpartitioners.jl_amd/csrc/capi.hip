@@ -170,8 +170,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
         }
     };
     dump_layer(1, cstA.p, false);
-    void *work = fast ? dp_total_work_new<TC>() : nullptr;
-    struct WorkGuard { void *w; ~WorkGuard() { if (w) dp_total_work_free<TC>(w); } } wg{work};
+    void *work = fast ? dp_total_work_get<TC>(A) : nullptr;       // (kept in the handle between calls)
     TC *prevc = cstA.p, *curc = cstB.p;
     for (int64_t k = 2; k <= K; k++) {
         int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
@@ -211,7 +210,7 @@ struct DpRun : DpBase {
     bool fast = false, need_self = false;
     void *work = nullptr;
     DBuf<int32_t> ptr;                         // K x (n+1); only the tile rows of layers >= 2 are meaningful
-    ~DpRun() { if (work) dp_total_work_free<TC>(work); }
+    ~DpRun() {}                                  // (the layer scratch belongs to the handle)
     TC alpha_of(int64_t k) const
     {
         if (order == CP_ORDER_SPLITTER && !alpha_k_host.empty() && k >= 1 && k <= (int64_t)alpha_k_host.size()) return alpha_k_host[(size_t)k - 1];
@@ -241,7 +240,7 @@ static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, 
     build_dev_model<TC>(&D->mdl, D->HM, A->stream);
     D->ptr.alloc((size_t)K * (size_t)(n + 1));
     CP_HIP(hipMemsetAsync(D->ptr.p, 0, D->ptr.bytes(), A->stream));
-    if (D->fast) D->work = dp_total_work_new<TC>();
+    if (D->fast) D->work = dp_total_work_get<TC>(A);
     CP_HIP(hipStreamSynchronize(A->stream));
     *out = D.release();
     return CP_OK;
@@ -444,6 +443,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "prof_only")) { g_prof_only = (int)value; return CP_OK; }
     if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
+    if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     set_error("unknown option");

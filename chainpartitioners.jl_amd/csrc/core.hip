@@ -14,7 +14,7 @@ ProfSlot g_prof[PROF_NSLOTS] = {
     {"dp_lpass", 0, 0, 0}, {"dp_open_segments", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
     {"scan", 0, 0, 0}, {"dp_tile_carry", 0, 0, 0}, {"dp_span_fix", 0, 0, 0}, {"dp_combine", 0, 0, 0},
     {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
-    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}, {"dp_lpass_gap", 0, 0, 0}};
+    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}, {"dp_lpass_gap", 0, 0, 0}, {"dp_round_a", 0, 0, 0}};
 bool g_prof_on = false;
 int g_prof_only = -1;
 std::vector<ProfPending> g_prof_pending;
@@ -370,6 +370,7 @@ void ensure_self(cp_csr_s *A)
 void drop_cache(cp_csr_s *A)
 {
     A->have_links = false; A->have_self = false;
+    for (int i = 0; i < 2; i++) if (A->dp_work[i] && A->dp_work_reset_fn[i]) A->dp_work_reset_fn[i](A->dp_work[i]);
     A->col.release(); A->prev.release(); A->next.release(); A->rfirst.release(); A->rlast.release();
     A->pos32.release(); A->fpos32.release(); A->lpos32.release();
     A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release(); A->ffirst.release();

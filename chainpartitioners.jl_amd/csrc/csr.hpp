@@ -28,6 +28,12 @@ struct cp_csr_s {
     cpk::DBuf<int32_t> lfirst;  // #nonempty rows : first column of rows whose last column is c
     cpk::DBuf<int32_t> ffirst;  // #nonempty rows : the bucket (= first column) of every flast entry
     int64_t nrows_nonempty = 0;
+    // scratch of the total-cost DP layers ([0]: Int64 costs, [1]: Float64 costs), kept between calls: several GB that would
+    // otherwise be allocated and freed by every partition call.  Its pattern-dependent parts are dropped with the cache.
+    void *dp_work[2] = {nullptr, nullptr};
+    void (*dp_work_free_fn[2])(void *) = {nullptr, nullptr};
+    void (*dp_work_reset_fn[2])(void *) = {nullptr, nullptr};
+    ~cp_csr_s() { for (int i = 0; i < 2; i++) if (dp_work[i] && dp_work_free_fn[i]) dp_work_free_fn[i](dp_work[i]); }
 };
 
 namespace cpk {

@@ -9,6 +9,7 @@ namespace cpk {
 template <typename TC>
 void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work,
                     int64_t rlo, int64_t rhi);      // computes rows r in [rlo, rhi] (0-based); the full range is [0, n]
+template <typename TC> void *dp_total_work_get(cp_csr_s *A);      // the handle's scratch for cost type TC (created on first use)
 template <typename TC> void *dp_total_work_new();
 template <typename TC> void dp_total_work_free(void *w);
 
@@ -39,6 +40,7 @@ template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
 extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <= gap_tau (-1: none) for tasks of >= gap_min candidates
+extern int64_t g_opt_ra_cache;                 // 1: round A from counts computed once per partition
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
 extern int64_t g_opt_rpass_ch;                 // columns per wave in k_rpass_wave (power of two >= 16)

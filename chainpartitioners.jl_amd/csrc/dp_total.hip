@@ -1539,6 +1539,153 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t
     ptr[r] = (int32_t)bp;
 }
 
+// ------------------------------------------------------------------ round A from cached counts
+// Round A (row r against its lowest block [r - 2^b, r), b = ctz(r)) is the one round whose candidate ranges do not depend on
+// the layer: nets(p, r) for all its (row, candidate) pairs -- sum_r 2^ctz(r) = n log2(n) / 2 values -- is computed ONCE per
+// partition and kept (4 B each); a layer then evaluates round A by streaming counts, W and pos (16 B per candidate instead
+// of the candidate's whole column).  Elements are stored level by level (b), row by row, candidate p = r - 1 - i at index i;
+// every level is padded to whole tiles of LT elements.
+struct RATab { int32_t nbits, _pad; int64_t n; int64_t tbase[33]; int64_t rbase[33]; };      // tiles of level b: [tbase[b], tbase[b+1]); rows of the levels >= 9: [rbase[b], rbase[b+1])
+
+__device__ __forceinline__ bool ra_decode(const RATab &T, int64_t tile, int j, int &b, int64_t &r, int64_t &p, int64_t &i)
+{
+    b = 0;
+    while (tile >= T.tbase[b + 1]) b++;                     // (uniform per tile)
+    int64_t e = (tile - T.tbase[b]) * LT + j;               // element inside the level
+    int64_t u = e >> b;
+    i = e & (((int64_t)1 << b) - 1);
+    r = ((u << 1) | 1) << b;
+    p = r - 1 - i;
+    return r <= T.n;
+}
+
+// d[E] = #{q in column p : next[q] >= r} (d2: rows whose first column is p and whose last column is < r)
+__global__ void __launch_bounds__(256) k_ra_colcount(RATab T, const int32_t *__restrict__ pos, const int32_t *__restrict__ next,
+                                                     const int32_t *__restrict__ fpos, const int32_t *__restrict__ flast,
+                                                     int32_t *__restrict__ d, int32_t *__restrict__ d2)
+{
+    int b; int64_t r, p, i;
+    bool ok = ra_decode(T, blockIdx.x, threadIdx.x, b, r, p, i);
+    int64_t E = (int64_t)blockIdx.x * LT + threadIdx.x;
+    int32_t c = 0, c2 = 0;
+    if (ok) {
+        int32_t rr = (int32_t)r;
+        for (int32_t q = pos[p], q1 = pos[p + 1]; q < q1; q++) c += (next[q] >= rr);
+        if (d2) for (int32_t q = fpos[p], q1 = fpos[p + 1]; q < q1; q++) c2 += (flast[q] < rr);
+    }
+    d[E] = c;
+    if (d2) d2[E] = c2;
+}
+
+// c[E] = sum of d over the row's elements 0 .. i  (G = exclusive prefix sums of d over all elements)
+__global__ void __launch_bounds__(256) k_ra_final(RATab T, const int64_t *__restrict__ G, int32_t *__restrict__ c)
+{
+    int b; int64_t r, p, i;
+    ra_decode(T, blockIdx.x, threadIdx.x, b, r, p, i);
+    int64_t E = (int64_t)blockIdx.x * LT + threadIdx.x;
+    c[E] = (int32_t)(G[E + 1] - G[E - i]);
+}
+
+template <typename TC, bool HYP>
+__device__ __forceinline__ bool ra_takes(const Best<TC, HYP> &x, const Best<TC, HYP> &c)      // c replaces x: smaller value, or equal value and larger p
+{
+    return (x.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < x.v || (c.v == x.v && c.p > x.p)));
+}
+
+// one wave per tile of LT elements; a lane holds four consecutive elements.  Rows of up to LT candidates (b <= 8) lie inside
+// one tile and are finished here; longer rows leave one partial per tile for k_ra_merge.
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_ra_layer(RATab T, int64_t ntile, const int32_t *__restrict__ cnt, const int32_t *__restrict__ cnt2,
+                                                  const int32_t *__restrict__ pos, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
+                                                  Best<TC, HYP> *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
+    const int64_t n1 = T.n + 1;
+    const int64_t E0 = tile * LT + 4 * lane;
+    const int4 c4 = *reinterpret_cast<const int4 *>(cnt + E0);
+    int4 d4 = make_int4(0, 0, 0, 0);
+    if (HYP) d4 = *reinterpret_cast<const int4 *>(cnt2 + E0);
+    int b = 0;
+    Best<TC, HYP> cand[4];
+    int64_t rk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int64_t r, p, i;
+        bool ok = ra_decode(T, tile, 4 * lane + k, b, r, p, i);
+        rk[k] = ok ? r : 0;
+        best_clear(cand[k]);
+        if (ok) {
+            int32_t c = k == 0 ? c4.x : k == 1 ? c4.y : k == 2 ? c4.z : c4.w, c2 = k == 0 ? d4.x : k == 1 ? d4.y : k == 2 ? d4.z : d4.w;
+            cand[k].v = cadd(W[p], dm_apply(M, alpha, r - p, (int64_t)(pos[r] - pos[p]), (int64_t)c, (int64_t)c2));
+            cand[k].p = (int32_t)p; cand[k].nn = c; best_set_nl(cand[k], c2);
+        }
+    }
+    if (b < 2) {                                            // rows of one or two candidates: finished inside the lane
+        const int per = 1 << b;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((k & (per - 1)) != 0 || rk[k] == 0) continue;
+            Best<TC, HYP> x = cand[k];
+            if (per == 2 && ra_takes(x, cand[k + 1 < 4 ? k + 1 : 3])) x = cand[k + 1 < 4 ? k + 1 : 3];
+            int64_t rw = (int64_t)b * n1 + PR(rk[k]);
+            opt[rw] = x.p; nnopt[rw] = x.nn;
+            if (HYP) nlopt[rw] = best_nl(x);
+        }
+        return;
+    }
+    Best<TC, HYP> x = cand[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) if (ra_takes(x, cand[k])) x = cand[k];
+    const int lpr = b >= 8 ? 64 : (1 << (b - 2));          // lanes per row
+    for (int o = 1; o < lpr; o <<= 1) {                     // butterfly inside the row's lanes: every lane ends with the winner
+        Best<TC, HYP> c; best_clear(c);
+        c.v = shfl64(x.v, lane ^ o); c.p = __shfl(x.p, lane ^ o); c.nn = __shfl(x.nn, lane ^ o);
+        if (HYP) best_set_nl(c, __shfl(best_nl(x), lane ^ o));
+        if (ra_takes(x, c)) x = c;
+    }
+    if ((lane & (lpr - 1)) == 0) {
+        if (b <= 8) {
+            if (rk[0]) {
+                int64_t rw = (int64_t)b * n1 + PR(rk[0]);
+                opt[rw] = x.p; nnopt[rw] = x.nn;
+                if (HYP) nlopt[rw] = best_nl(x);
+            }
+        } else {
+            part[tile - T.tbase[9]] = x;
+        }
+    }
+}
+
+// rows of more than LT candidates (b >= 9): one wave per row merges the row's tile partials
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_ra_merge(RATab T, int64_t nrow, const Best<TC, HYP> *__restrict__ part,
+                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nrow) return;
+    int b = 9;
+    while (w >= T.rbase[b + 1]) b++;
+    const int64_t u = w - T.rbase[b], r = ((u << 1) | 1) << b, n1 = T.n + 1;
+    const int64_t t0 = T.tbase[b] + (u << (b - 8)) - T.tbase[9], cntt = (int64_t)1 << (b - 8);
+    Best<TC, HYP> x; best_clear(x);
+    for (int64_t k = lane; k < cntt; k += 64) { Best<TC, HYP> c = part[t0 + k]; if (ra_takes(x, c)) x = c; }
+    for (int o = 32; o > 0; o >>= 1) {
+        Best<TC, HYP> c; best_clear(c);
+        c.v = shfl64(x.v, lane ^ o); c.p = __shfl(x.p, lane ^ o); c.nn = __shfl(x.nn, lane ^ o);
+        if (HYP) best_set_nl(c, __shfl(best_nl(x), lane ^ o));
+        if (ra_takes(x, c)) x = c;
+    }
+    if (lane == 0 && r <= T.n) {
+        int64_t rw = (int64_t)b * n1 + PR(r);
+        opt[rw] = x.p; nnopt[rw] = x.nn;
+        if (HYP) nlopt[rw] = best_nl(x);
+    }
+}
+
 // ------------------------------------------------------------------ end of a round's counting phase
 // One thread: derives the tile count and checks the scan totals against the capacities of the buffers the host sized from
 // its prediction (the previous layer); on overflow the round's work is dropped and the flag makes the host redo the layer.
@@ -1566,6 +1713,10 @@ struct LayerWork {
     DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2, o_wide, o_hi;
     DBuf<Best<TC, true>> o_sub;                         // gap passes: segment winners of the tiles with specials, [tile][SMAX + 1]
     DBuf<int32_t> o_spv;                                // ... and the specials between them
+    // round A from cached counts
+    bool ra_built = false; RATab ra_tab; int64_t ra_ntile = 0, ra_nrow = 0;
+    DBuf<int32_t> ra_c, ra_c2;
+    DBuf<Best<TC, true>> ra_part;
     DBuf<int2> g_slot;                                  // segment slot -> {task, segment}
     DBuf<int2> g_list;                                  // gap tasks of more than GAPSEG tiles: {task, first segment slot}
     DBuf<char> g_seg;                                   // their segment records (GapSegRec)
@@ -1581,7 +1732,7 @@ struct LayerWork {
         if (o_rec.n >= NT && o_rec.n > 0) return;
         size_t c = NT > 0 ? NT : 1;
         o_rec.alloc(c); o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c); o_hi.alloc(c); o_spec.alloc(c);
-        if (g_opt_gap_tau >= 0) { o_sub.alloc(c * (SMAX + 1)); o_spv.alloc(c * (SMAX + 1)); }
+        o_sub.alloc(c * (SMAX + 1)); o_spv.alloc(c * (SMAX + 1));
         if (hyp) { o_tileS2.alloc(c); o_tilePS2.alloc(c + 1); }
     }
     void ensure_flat(size_t T) {                        // per-step and per-tile arrays of the flattened tasks
@@ -1680,6 +1831,44 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     }
 }
 
+// builds the cached round-A counts (once per partition: they depend on the pattern only)
+template <typename TC>
+static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n;
+    const bool hyp = Wk.hyp;
+    RATab &T = Wk.ra_tab;
+    memset(&T, 0, sizeof(T));
+    T.nbits = Wk.nbits; T.n = n;
+    int64_t tb = 0, rb = 0;
+    for (int b = 0; b < 33; b++) {
+        T.tbase[b] = tb; T.rbase[b] = rb;
+        if (b >= Wk.nbits) continue;
+        int64_t nrows = ((n >> b) + 1) >> 1;
+        tb += cdiv(nrows << b, LT);
+        if (b >= 9) rb += nrows;
+    }
+    Wk.ra_ntile = tb; Wk.ra_nrow = rb;
+    const size_t total = (size_t)tb * LT;
+    Wk.ra_c.alloc(total + 8);
+    if (hyp) Wk.ra_c2.alloc(total + 8);
+    Wk.ra_part.alloc((size_t)std::max<int64_t>(1, tb - T.tbase[9]));
+    if (tb <= 0) { Wk.ra_built = true; return; }
+    DBuf<int64_t> G(total + 1), scratch;
+    hipLaunchKernelGGL(k_ra_colcount, dim3((unsigned)tb), dim3(LT), 0, s, T, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,
+                       hyp ? A->flast.p : (const int32_t *)nullptr, Wk.ra_c.p, hyp ? Wk.ra_c2.p : (int32_t *)nullptr);
+    exclusive_scan_i32(Wk.ra_c.p, G.p, (int64_t)total, scratch, s);
+    hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c.p);
+    if (hyp) {
+        exclusive_scan_i32(Wk.ra_c2.p, G.p, (int64_t)total, scratch, s);
+        hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c2.p);
+    }
+    CP_HIP(hipGetLastError());
+    CP_HIP(hipStreamSynchronize(s));       // G and scratch die here
+    Wk.ra_built = true;
+}
+
 // Runs the rounds of one layer.  `spec`: the per-round counts of the PREVIOUS layer (Wk.pred) size the grids, the buffers and
 // decide which stages are launched; every kernel reads its true loop bounds from the device (RoundCounts) and walks them with
 // grid strides, so a wrong prediction costs time, never correctness -- except a stage skipped or a buffer too small, which
@@ -1712,6 +1901,26 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi);
         else make_round(R, false, nbits - rd, nbits, n, rlo, rhi);
+        if (rd == 0 && g_opt_ra_cache && rlo <= 1 && rhi >= n && n >= 1) {
+            // a full layer: round A of the rows' lowest blocks from the cached counts; what is left of round A below is the
+            // last row in its upper planes
+            if (!Wk.ra_built) { ProfScope ps(PROF_LINKS, s, 0.0); ra_build<TC>(A, Wk); }
+            ProfScope ps(PROF_RA, s, 16.0 * (double)Wk.ra_ntile * LT);
+            if (hyp) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p, Wk.ra_c2.p,
+                                   A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
+                if (Wk.ra_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(Wk.ra_nrow, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_nrow,
+                                                       Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
+            } else {
+                auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, false>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p,
+                                   (const int32_t *)nullptr, A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa);
+                if (Wk.ra_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(Wk.ra_nrow, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_nrow,
+                                                       pa, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
+            }
+            CP_HIP(hipGetLastError());
+            R.a_nmain = 0; R.ntask = R.nextra + R.nlast;
+        }
         if (R.ntask <= 0) continue;
         RoundCounts *rc = Wk.rc.p + rd;
         const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
@@ -1964,7 +2173,8 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     while (((int64_t)1 << nbits) <= n) nbits++;
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
-        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false;
+        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false;
+        Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
         if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
@@ -1993,6 +2203,16 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
 }
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
+template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
+template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; }
+template <typename TC> void *dp_total_work_get(cp_csr_s *A)
+{
+    const int i = sizeof(TC) == sizeof(double) && ((TC)0.5 != (TC)0) ? 1 : 0;
+    if (!A->dp_work[i]) { A->dp_work[i] = new LayerWork<TC>(); A->dp_work_free_fn[i] = work_free_fn<TC>; A->dp_work_reset_fn[i] = work_reset_fn<TC>; }
+    return A->dp_work[i];
+}
+template void *dp_total_work_get<int64_t>(cp_csr_s *);
+template void *dp_total_work_get<double>(cp_csr_s *);
 template <typename TC> void dp_total_work_free(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
 
 template void dp_total_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, void *, int64_t, int64_t);
