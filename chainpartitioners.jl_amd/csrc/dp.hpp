@@ -43,6 +43,7 @@ extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <
 extern int64_t g_opt_ra_cache;                 // 1: round A from counts computed once per partition
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
+extern int64_t g_opt_rpass_small_tau;           // rounds tau <= this use one lane per row in the right-part pass
 extern int64_t g_opt_rpass_ch;                 // columns per wave in k_rpass_wave (power of two >= 16)
 extern int64_t g_opt_own_min;                  // tasks with at least this many steps get tiles of their own (>= 64)
 extern int64_t g_opt_short_t, g_opt_short_e;   // k_setup_short: tasks with <= short_t candidates and <= short_e link entries finish in setup

@@ -1818,7 +1818,7 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     int64_t u1 = ((rmax >> tau) + 1) >> 1;                              // #rows <= rmax
     int64_t nrows = u1 - u0;
     if (nrows <= 0) return;
-    if (tau <= 3) {
+    if (tau <= g_opt_rpass_small_tau) {
         if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
     } else {

@@ -132,6 +132,37 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
                 assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, om, M_)
 
 
+# every tunable of the layer driver selects between code paths that must all produce the reference's tables:
+#   nospec     1: every round waits for its exact counts / 0: grids and buffers sized from the previous layer's counts
+#   gap_tau    rounds tau <= gap_tau finish whole gaps in one pass (-1: plain divide and conquer everywhere)
+#   gap_min    shortest task taken by a gap pass
+#   ra_cache   round A from counts computed once per partition / recomputed by every layer
+#   dbg 512    every gap tile takes the entry-by-entry path (as if it held too many specials)
+LAYER_OPTIONS = [{"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 0}, {"gap_tau": 3, "gap_min": 8}, {"gap_tau": 8, "gap_min": 16}, {"gap_tau": 12},
+                 {"ra_cache": 0}, {"ra_cache": 0, "gap_tau": -1, "nospec": 1}, {"dbg": 512}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
+                 {"rpass_small_tau": 6}, {"rpass_ch": 16}]
+LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 5, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 3, "rpass_ch": 512}
+
+
+@pytest.mark.parametrize("oi", range(len(LAYER_OPTIONS)))
+def test_layer_driver_options_bit_exact(hip, orc, oi):
+    opts = LAYER_OPTIONS[oi]
+    mats_ = list(golden_matrices().values())[-2:] + [suitesparse_shaped(5000, 8, 1), banded(2500, 6, 0.5, 3), suitesparse_shaped(1025, 5, 7)]
+    try:
+        for k, v in opts.items():
+            assert hip.set_option(k, v) == 0
+        for A in mats_:
+            for mdl in (MODELS[0], MODELS[3], MODELS[6], MODELS[7]):
+                mm = mdl.marshal()
+                rc1, p1, c1 = hip.dynamic_tables(A, 5, 0, mm, None)
+                rc2, p2, c2 = orc.dynamic_tables(A, 5, 0, mm, None)
+                assert rc1 == 0 and rc2 == 0, hip.last_error()
+                assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (opts, A, mdl)
+    finally:
+        for k, v in LAYER_DEFAULTS.items():
+            hip.set_option(k, v)
+
+
 def test_plain_c_client_runs(hip):
     """The C ABI driven from a C program (examples/c_abi_demo.c) in a child process: no Python between caller and library."""
     import os, subprocess
