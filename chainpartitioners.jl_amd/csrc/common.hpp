@@ -94,6 +94,14 @@ void prof_collect();   // resolve pending event pairs (after a stream sync)
 void exclusive_scan_i32(const int32_t *in, int64_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s);
 void exclusive_scan_i32_devn(const int32_t *in, int64_t *out, const int32_t *n_dev, int64_t n_max, int64_t *total_out,
                              DBuf<int64_t> &scratch, hipStream_t s);
+// Single-launch form (decoupled look-back) for the scans inside the DP rounds: dozens of small scans per layer, where three
+// launches each are most of the cost.  Sums must stay below 2^40 (they are step / tile counts).  One ScanWS per stream of work.
+struct ScanWS {
+    DBuf<unsigned long long> st;      // per block: [epoch:22][status:2][value:40]
+    DBuf<uint32_t> ticket;            // blocks take their index here (a block only waits for blocks that already run)
+    uint32_t epoch = 0, tbase = 0;
+};
+void exclusive_scan_i32_lb(const int32_t *in, int64_t *out, const int32_t *n_dev, int64_t n_max, int64_t *total_out, ScanWS &ws, hipStream_t s);
 void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s);
 
 // wave64 helpers

@@ -134,6 +134,74 @@ void exclusive_scan_i32_devn(const int32_t *in, int64_t *out, const int32_t *n_d
     CP_HIP(hipGetLastError());
 }
 
+// ---- single-launch scan: chained blocks, decoupled look-back
+__device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, uint32_t status, int64_t v)
+{
+    return ((unsigned long long)epoch << 42) | ((unsigned long long)status << 40) | ((unsigned long long)v & 0xFFFFFFFFFFull);
+}
+__global__ void __launch_bounds__(SCAN_T) k_scan_lb(const int32_t *__restrict__ in, int64_t *__restrict__ out, const int32_t *__restrict__ n_dev,
+                                                    int64_t *__restrict__ total_out, unsigned long long *__restrict__ st, uint32_t *__restrict__ ticket,
+                                                    uint32_t tbase, uint32_t epoch)
+{
+    __shared__ int64_t sh[SCAN_T];
+    __shared__ uint32_t s_bid;
+    __shared__ int64_t s_prefix;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u) - tbase;
+    __syncthreads();
+    const int64_t bid = s_bid, n = *n_dev, blast = n / SCAN_TILE;      // the block holding index n writes the total
+    if (bid > blast) return;
+    int64_t base = bid * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    int32_t v[SCAN_I];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        int64_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int64_t tot = sh[SCAN_T - 1];
+        int64_t prefix = 0;
+        if (bid > 0) {
+            __hip_atomic_store(&st[bid], lb_pack(epoch, 1, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t j = bid - 1;; ) {
+                unsigned long long w = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(w >> 42) != epoch || ((w >> 40) & 3ull) == 0ull) { __builtin_amdgcn_s_sleep(1); continue; }      // not there yet
+                prefix += (int64_t)(w & 0xFFFFFFFFFFull);
+                if (((w >> 40) & 3ull) == 2ull) break;              // an inclusive prefix: done
+                j--;
+            }
+        }
+        __hip_atomic_store(&st[bid], lb_pack(epoch, 2, prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = prefix;
+        if (bid == blast) { out[n] = prefix + tot; if (total_out) *total_out = prefix + tot; }
+    }
+    __syncthreads();
+    int64_t run = s_prefix + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_I; k++) if (base + k < n) { out[base + k] = run; run += v[k]; }
+}
+
+void exclusive_scan_i32_lb(const int32_t *in, int64_t *out, const int32_t *n_dev, int64_t n_max, int64_t *total_out, ScanWS &ws, hipStream_t s)
+{
+    if (n_max <= 0) n_max = 1;
+    const int64_t nb = n_max / SCAN_TILE + 1;                       // (covers the block that holds index n when n == n_max)
+    if (ws.st.n < (size_t)nb || !ws.ticket.p) {
+        ws.st.alloc((size_t)nb + 1024); ws.ticket.alloc(1);
+        CP_HIP(hipMemsetAsync(ws.st.p, 0, ws.st.bytes(), s));
+        CP_HIP(hipMemsetAsync(ws.ticket.p, 0, sizeof(uint32_t), s));
+        ws.epoch = 0; ws.tbase = 0;
+    }
+    if (++ws.epoch >= (1u << 22)) { CP_HIP(hipMemsetAsync(ws.st.p, 0, ws.st.bytes(), s)); ws.epoch = 1; }
+    hipLaunchKernelGGL(k_scan_lb, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, n_dev, total_out, ws.st.p, ws.ticket.p, ws.tbase, ws.epoch);
+    ws.tbase += (uint32_t)nb;
+    CP_HIP(hipGetLastError());
+}
+
 void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int64_t> &scratch, hipStream_t s)
 {
     if (n <= 0) { CP_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), s)); return; }

@@ -1704,6 +1704,7 @@ struct LayerWork {
     DBuf<int32_t> nlopt, crl, tS0l, loc2, tileS2;        // hyperedge-cut: second (self-net) count
     DBuf<uint8_t> tb;
     DBuf<int64_t> offs, scratch, taskR, tilePS, tilePS2, tile_t0;
+    ScanWS scanws;                                      // single-launch scans of the rounds
     DBuf<Best<TC, true>> partL, partR;                  // sized for the larger record; reinterpreted per variant
     DBuf<int32_t> open_list, fix_list;                  // tiles of long spans (k_span_short -> k_open / k_fix)
     DBuf<int4> tile_rec;                                // {first column, row, -, interior?} per tile (k_tile_t0)
@@ -1869,6 +1870,8 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
     Wk.ra_built = true;
 }
 
+constexpr int64_t LB_MAX = 1 << 20;      // largest scan (elements) done in a single launch
+
 // Runs the rounds of one layer.  `spec`: the per-round counts of the PREVIOUS layer (Wk.pred) size the grids, the buffers and
 // decide which stages are launched; every kernel reads its true loop bounds from the device (RoundCounts) and walks them with
 // grid strides, so a wrong prediction costs time, never correctness -- except a stage skipped or a buffer too small, which
@@ -1961,9 +1964,15 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         {
             // both scans read their element count on the device
             ProfScope ps(PROF_SCAN, s, 12.0 * (double)R.ntask);
-            exclusive_scan_i32_devn(Wk.len.p, Wk.offs.p, &rc->nlong, R.ntask, &rc->T, Wk.scratch, s);
+            // (single-launch scans take their block index from one counter: fine for a few hundred blocks, not for 27 000)
+            if (R.ntask <= LB_MAX) exclusive_scan_i32_lb(Wk.len.p, Wk.offs.p, &rc->nlong, R.ntask, &rc->T, Wk.scanws, s);
+            else exclusive_scan_i32_devn(Wk.len.p, Wk.offs.p, &rc->nlong, R.ntask, &rc->T, Wk.scratch, s);
             if (own_tiles)
-                exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, std::min<int64_t>(R.ntask, (int64_t)Wk.o_ntl.n), &rc->NT, Wk.scratch, s);
+                {
+                    const int64_t nm = std::min<int64_t>(R.ntask, (int64_t)Wk.o_ntl.n);
+                    if (nm <= LB_MAX) exclusive_scan_i32_lb(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, nm, &rc->NT, Wk.scanws, s);
+                    else exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, nm, &rc->NT, Wk.scratch, s);
+                }
             hipLaunchKernelGGL(k_round_finish, dim3(1), dim3(1), 0, s, rc, spec ? (int64_t)Wk.loc.n : INT64_MAX, spec ? (int64_t)Wk.o_rec.n : INT64_MAX);
         }
         if (!spec) {
@@ -2006,8 +2015,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             {
                 ProfScope ps(PROF_CARRY, s, 12.0 * (double)P.NT);
                 const int32_t *ntp = reinterpret_cast<const int32_t *>(&rc->NT);       // (NT < 2^31: the low word)
-                exclusive_scan_i32_devn(Wk.o_tileS.p, Wk.o_tilePS.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
-                if (hyp) exclusive_scan_i32_devn(Wk.o_tileS2.p, Wk.o_tilePS2.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scratch, s);
+                exclusive_scan_i32_lb(Wk.o_tileS.p, Wk.o_tilePS.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scanws, s);
+                if (hyp) exclusive_scan_i32_lb(Wk.o_tileS2.p, Wk.o_tilePS2.p, ntp, (int64_t)Wk.o_tileS.n, nullptr, Wk.scanws, s);
             }
             if (gap) {
                 // every row of the gaps gets its winner: one wave per (task, 64 rows); tasks of more than GAPSEG tiles in two steps
@@ -2099,8 +2108,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         note(rd, 1, PROF_EXPAND);
         {
             ProfScope ps(PROF_CARRY, s, 12.0 * (double)cdiv(P.T, LT));
-            exclusive_scan_i32_devn(Wk.tileS.p, Wk.tilePS.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scratch, s);
-            if (hyp) exclusive_scan_i32_devn(Wk.tileS2.p, Wk.tilePS2.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scratch, s);
+            exclusive_scan_i32_lb(Wk.tileS.p, Wk.tilePS.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scanws, s);
+            if (hyp) exclusive_scan_i32_lb(Wk.tileS2.p, Wk.tilePS2.p, &rc->ntile, (int64_t)Wk.tileS.n, nullptr, Wk.scanws, s);
         }
         unsigned wgrid = (unsigned)std::min<int64_t>(cdiv(gtile, 4), 8192);     // the wave kernels walk work lists
         {
