@@ -85,6 +85,23 @@ def cpu_baseline(K, mean_deg, budget_s=25.0):
     return a, samples
 
 
+def measure_copy_gbs(dev):
+    """Device-to-device copy bandwidth of this box (bytes read + bytes written per second), the practical HBM ceiling."""
+    a = torch.empty(1 << 28, dtype=torch.int32, device=dev)      # 1 GiB
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    return 2.0 * (1 << 30) / (ms * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +165,7 @@ def main():
 
     # The per-kernel breakdown (HIP events around every launch group: ~40 records per DP round) is taken on an UNTIMED step;
     # the timed region keeps events around the dominant kernel only (2 per round), as the roofline line needs them live.
+    copy_gbs = measure_copy_gbs(dev)
     for _ in range(max(args.warmup - 1, 0)):
         step()
     hip.prof_reset()
@@ -207,7 +225,7 @@ def main():
         # HBM traffic of the dominant kernel from the PMC counters: collected by tools/pmc_lpass.sh under rocprofv3
         # (FETCH_SIZE and WRITE_SIZE in separate passes) and committed under profiles/; valid for the default workload only
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01d_pmc_%s.json" % kname)
+        pmc_path = os.path.join(ROOT, "profiles", "r01e_pmc_%s.json" % kname)
         if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
             traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
         out = {
@@ -221,6 +239,7 @@ def main():
                        "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
             "roofline": {"bound": "hbm", "kernel": "%s (%s)" % (dom, kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_gbs": copy_gbs,      # this box's device-to-device copy rate (read + write bytes), SURVEY 8(d)
                          "avg_launch_ms": avg_ms, "launches_per_step": ex["launches"] / args.steps,
                          "alg_bytes_per_launch": bytes_per_launch,
                          "whole_path": {"alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9,

@@ -1608,13 +1608,17 @@ __global__ void __launch_bounds__(256) k_ra_layer(RATab T, int64_t ntile, const 
     const int4 c4 = *reinterpret_cast<const int4 *>(cnt + E0);
     int4 d4 = make_int4(0, 0, 0, 0);
     if (HYP) d4 = *reinterpret_cast<const int4 *>(cnt2 + E0);
+    // the lane's first element is decoded; from level 2 on the other three are the next candidates of the same row
     int b = 0;
+    int64_t r0, p0, i0;
+    const bool ok0 = ra_decode(T, tile, 4 * lane, b, r0, p0, i0);
     Best<TC, HYP> cand[4];
     int64_t rk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int64_t r, p, i;
-        bool ok = ra_decode(T, tile, 4 * lane + k, b, r, p, i);
+        int64_t r = r0, p = p0 - k;
+        bool ok = ok0;
+        if (b < 2) { int bb; int64_t ii; ok = ra_decode(T, tile, 4 * lane + k, bb, r, p, ii); }      // (uniform branch)
         rk[k] = ok ? r : 0;
         best_clear(cand[k]);
         if (ok) {
