@@ -351,10 +351,10 @@ void ensure_links(cp_csr_s *A)
     int64_t N = A->N, n = A->n, m = A->m;
     size_t Na = (size_t)(N > 0 ? N : 1);
     ProfScope ps(PROF_LINKS, s, 8.0 * (double)N + 8.0 * (double)(n + 1));
-    A->col.alloc(Na); A->prev.alloc(Na + 8); A->next.alloc(Na + 8);     // +8: 16-byte vector loads may over-read the tail
-    A->rfirst.alloc((size_t)(m > 0 ? m : 1)); A->rlast.alloc((size_t)(m > 0 ? m : 1));
-    A->tpos.alloc((size_t)m + 1); A->tq.alloc(Na);
-    A->pos32.alloc((size_t)n + 1);
+    A->col.ensure(Na); A->prev.ensure(Na + 8); A->next.ensure(Na + 8);     // +8: 16-byte vector loads may over-read the tail
+    A->rfirst.ensure((size_t)(m > 0 ? m : 1)); A->rlast.ensure((size_t)(m > 0 ? m : 1));
+    A->tpos.ensure((size_t)m + 1); A->tq.ensure(Na);
+    A->pos32.ensure((size_t)n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->pos.p, A->pos32.p, n + 1);
     CP_HIP(hipMemsetAsync(A->rfirst.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
     CP_HIP(hipMemsetAsync(A->rlast.p, 0xFF, sizeof(int32_t) * (size_t)(m > 0 ? m : 1), s));
@@ -414,20 +414,20 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_count_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p, cf.p, cl.p, m);
-    A->fpos.alloc((size_t)n + 1); A->lpos.alloc((size_t)n + 1);
+    A->fpos.ensure((size_t)n + 1); A->lpos.ensure((size_t)n + 1);
     exclusive_scan_i32(cf.p, A->fpos.p, n, scratch, s);
     exclusive_scan_i32(cl.p, A->lpos.p, n, scratch, s);
     int64_t tot = 0;
     CP_HIP(hipMemcpyAsync(&tot, A->fpos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     A->nrows_nonempty = tot;
-    A->flast.alloc((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.alloc((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
-    A->ffirst.alloc((size_t)(tot > 0 ? tot : 1) + 8);
+    A->flast.ensure((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
+    A->ffirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,
                                   A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, A->ffirst.p, m);
-    A->fpos32.alloc((size_t)n + 1); A->lpos32.alloc((size_t)n + 1);
+    A->fpos32.ensure((size_t)n + 1); A->lpos32.ensure((size_t)n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->fpos.p, A->fpos32.p, n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->lpos.p, A->lpos32.p, n + 1);
     CP_HIP(hipGetLastError());
@@ -439,9 +439,7 @@ void drop_cache(cp_csr_s *A)
 {
     A->have_links = false; A->have_self = false;
     for (int i = 0; i < 2; i++) if (A->dp_work[i] && A->dp_work_reset_fn[i]) A->dp_work_reset_fn[i](A->dp_work[i]);
-    A->col.release(); A->prev.release(); A->next.release(); A->rfirst.release(); A->rlast.release();
-    A->pos32.release(); A->fpos32.release(); A->lpos32.release();
-    A->tpos.release(); A->tq.release(); A->fpos.release(); A->flast.release(); A->lpos.release(); A->lfirst.release(); A->ffirst.release();
+    // (the arrays themselves stay allocated: the next build refills them -- a multi-GB hipFree + hipMalloc pair per call buys nothing)
 }
 
 }  // namespace cpk

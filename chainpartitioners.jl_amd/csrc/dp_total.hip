@@ -1721,6 +1721,7 @@ struct LayerWork {
     // round A from cached counts
     bool ra_built = false; RATab ra_tab; int64_t ra_ntile = 0, ra_nrow = 0;
     DBuf<int32_t> ra_c, ra_c2;
+    DBuf<int64_t> ra_G;                                 // prefix sums while the counts are built
     DBuf<Best<TC, true>> ra_part;
     DBuf<int2> g_slot;                                  // segment slot -> {task, segment}
     DBuf<int2> g_list;                                  // gap tasks of more than GAPSEG tiles: {task, first segment slot}
@@ -1856,11 +1857,12 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
     }
     Wk.ra_ntile = tb; Wk.ra_nrow = rb;
     const size_t total = (size_t)tb * LT;
-    Wk.ra_c.alloc(total + 8);
-    if (hyp) Wk.ra_c2.alloc(total + 8);
-    Wk.ra_part.alloc((size_t)std::max<int64_t>(1, tb - T.tbase[9]));
+    Wk.ra_c.ensure(total + 8);
+    if (hyp) Wk.ra_c2.ensure(total + 8);
+    Wk.ra_part.ensure((size_t)std::max<int64_t>(1, tb - T.tbase[9]));
     if (tb <= 0) { Wk.ra_built = true; return; }
-    DBuf<int64_t> G(total + 1), scratch;
+    DBuf<int64_t> &G = Wk.ra_G, &scratch = Wk.scratch;        // (kept with the layer scratch: 8 B per element)
+    G.ensure(total + 1);
     hipLaunchKernelGGL(k_ra_colcount, dim3((unsigned)tb), dim3(LT), 0, s, T, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,
                        hyp ? A->flast.p : (const int32_t *)nullptr, Wk.ra_c.p, hyp ? Wk.ra_c2.p : (int32_t *)nullptr);
     exclusive_scan_i32(Wk.ra_c.p, G.p, (int64_t)total, scratch, s);
@@ -1870,7 +1872,6 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
         hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c2.p);
     }
     CP_HIP(hipGetLastError());
-    CP_HIP(hipStreamSynchronize(s));       // G and scratch die here
     Wk.ra_built = true;
 }
 
