@@ -96,3 +96,21 @@ def test_config4_shape_width_limited_chunkers(hip):
         assert res["dynamic"] <= res["convex"]              # the DP is optimal; the stack algorithm need not be on this model
     finally:
         hip.csr_destroy(h)
+
+
+def test_fast_scheme_equals_literal_device_sweep_at_2e5(hip):
+    """Beyond the CPU oracle's reach: the O(n log^2 n) scheme (gap passes over gaps of hundreds of tiles, cached round A) against
+    the library's own literal O(n^2) device sweep at its size limit -- complete DP tables, bit for bit (tools/check_fast_vs_sweep.py)."""
+    from util import suitesparse_shaped, banded
+    n, K = 200000, 4
+    for A in (suitesparse_shaped(n, 10, 5), banded(n, 16, 0.5, 2)):
+        for mdl in (cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3)):
+            mm = mdl.marshal()
+            rc1, p1, c1 = hip.dynamic_tables(A, K, 0, mm, None)
+            hip.set_option("force_brute", 1)
+            try:
+                rc2, p2, c2 = hip.dynamic_tables(A, K, 0, mm, None)
+            finally:
+                hip.set_option("force_brute", 0)
+            assert rc1 == 0 and rc2 == 0, hip.last_error()
+            assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (A, mdl)
