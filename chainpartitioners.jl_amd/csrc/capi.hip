@@ -443,7 +443,6 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "prof_only")) { g_prof_only = (int)value; return CP_OK; }
     if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
-    if (!strcmp(name, "rc_tau")) { g_opt_rc_tau = value; return CP_OK; }
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "rpass_small_tau")) { g_opt_rpass_small_tau = value; return CP_OK; }
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }

@@ -391,7 +391,7 @@ __global__ void k_count_first_last(const int32_t *__restrict__ rfirst, const int
 __global__ void k_scatter_first_last(const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
                                      const int64_t *__restrict__ fpos, const int64_t *__restrict__ lpos,
                                      int32_t *__restrict__ cf, int32_t *__restrict__ cl,
-                                     int32_t *__restrict__ flast, int32_t *__restrict__ lfirst, int32_t *__restrict__ ffirst, int32_t *__restrict__ llast, int64_t m)
+                                     int32_t *__restrict__ flast, int32_t *__restrict__ lfirst, int32_t *__restrict__ ffirst, int64_t m)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m || rfirst[r] < 0) return;
@@ -401,7 +401,6 @@ __global__ void k_scatter_first_last(const int32_t *__restrict__ rfirst, const i
     ffirst[fpos[rfirst[r]] + a] = rfirst[r];
     int b = atomicAdd(&cl[rlast[r]], 1);
     lfirst[lpos[rlast[r]] + b] = rfirst[r];
-    llast[lpos[rlast[r]] + b] = rlast[r];
 }
 
 void ensure_self(cp_csr_s *A)
@@ -423,11 +422,11 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipStreamSynchronize(s));
     A->nrows_nonempty = tot;
     A->flast.ensure((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
-    A->ffirst.ensure((size_t)(tot > 0 ? tot : 1) + 8); A->llast.ensure((size_t)(tot > 0 ? tot : 1) + 8);
+    A->ffirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));
     if (m > 0) hipLaunchKernelGGL(k_scatter_first_last, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, s, A->rfirst.p, A->rlast.p,
-                                  A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, A->ffirst.p, A->llast.p, m);
+                                  A->fpos.p, A->lpos.p, cf.p, cl.p, A->flast.p, A->lfirst.p, A->ffirst.p, m);
     A->fpos32.ensure((size_t)n + 1); A->lpos32.ensure((size_t)n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->fpos.p, A->fpos32.p, n + 1);
     hipLaunchKernelGGL(k_narrow, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, A->lpos.p, A->lpos32.p, n + 1);

@@ -26,7 +26,6 @@ struct cp_csr_s {
     cpk::DBuf<int64_t> lpos;    // n+1
     cpk::DBuf<int32_t> fpos32, lpos32;   // 32-bit copies
     cpk::DBuf<int32_t> lfirst;  // #nonempty rows : first column of rows whose last column is c
-    cpk::DBuf<int32_t> llast;   // #nonempty rows : the bucket (= last column) of every lfirst entry
     cpk::DBuf<int32_t> ffirst;  // #nonempty rows : the bucket (= first column) of every flast entry
     int64_t nrows_nonempty = 0;
     // scratch of the total-cost DP layers ([0]: Int64 costs, [1]: Float64 costs), kept between calls: several GB that would

@@ -40,7 +40,6 @@ template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
 extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <= gap_tau (-1: none) for tasks of >= gap_min candidates
-extern int64_t g_opt_rc_tau;                   // rounds tau <= rc_tau take their right parts from the class lists (-1: none)
 extern int64_t g_opt_ra_cache;                 // 1: round A from counts computed once per partition
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)

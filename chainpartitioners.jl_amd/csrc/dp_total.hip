@@ -120,8 +120,7 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
         bool on = (r >> b) & 1;
         if (!__ballot(on)) continue;                           // wave-uniform
         used |= 1u << b;
-        // opt == nullptr: the block-independent counts of the class lists (rc_build): threshold = start (end) of the row's block b
-        int32_t v = opt ? opt[(int64_t)b * n1 + (on ? prL : 0)] : (int32_t)(((r >> b) << b) - (ge ? 0 : ((int64_t)1 << b)));
+        int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
         if (on) thr[b] = v;
     }
     if (!live) return;
@@ -166,7 +165,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
         thr[b] = ge ? INT32_MAX : INT32_MIN;
         if (b <= tau || b >= nbits) continue;
         bool on = (r >> b) & 1;
-        int32_t v = opt ? opt[(int64_t)b * n1 + (on ? prL : 0)] : (int32_t)(((r >> b) << b) - (ge ? 0 : ((int64_t)1 << b)));
+        int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
         if (on) thr[b] = v;
     }
     int64_t q0 = pos[c0], q1 = pos[c1];
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
                 v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
-            if (b <= tau || b >= nbits) continue;              // wave-uniform
+            if (b <= tau || b >= nbits || !((r >> b) & 1)) continue;      // wave-uniform: only the planes of this row's set bits
             int32_t t = thr[b];
             cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
         }
@@ -193,37 +192,6 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
             }
         }
     }
-}
-
-// ------------------------------------------------------------------ right parts from class lists (rounds tau <= rc_tau)
-// cr[b][r] = #{q in cols [rL, r) : prev[q] < B_b}, B_b inside the row's Fenwick block b.  The block a link value v falls in
-// (relative to ANY row whose range holds its column c, for every plane above the round) is the highest bit in which v and c
-// differ -- a constant of the entry, its CLASS.  Entries of a class above b lie left of block b: always counted; of a class below
-// b: never; only the entries of class b itself are compared with B_b.  So, once per partition (rc_build): the entries are
-// grouped by class (G: cell pointers [class][column], L: the values), and the always-counted part H[b][r] is tabulated by
-// one right-part pass with the block starts as thresholds.  A layer then takes  cr = H + #{class-b entries of the row's
-// columns below B}  inside k_setup_short -- a quarter of the entries per round, one comparison each, no pass of its own.
-// (ge lists, hyperedge costs: first columns of the rows bucketed by last column; counted iff first >= B; classes BELOW b always.)
-__global__ void __launch_bounds__(256) k_rc_count(int64_t N, int64_t n1, const int32_t *__restrict__ val, const int32_t *__restrict__ ecol,
-                                                  int32_t *__restrict__ cnt)
-{
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
-    int32_t v = val[q], c = ecol[q];
-    if (v < 0 || v == c) return;                            // no previous occurrence / a one-column row: no class
-    int cls = 31 - __clz(v ^ c);
-    atomicAdd(&cnt[(int64_t)cls * n1 + c], 1);
-}
-__global__ void __launch_bounds__(256) k_rc_scatter(int64_t N, int64_t n1, const int32_t *__restrict__ val, const int32_t *__restrict__ ecol,
-                                                    const int32_t *__restrict__ G, int32_t *__restrict__ fill, int32_t *__restrict__ L)
-{
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
-    int32_t v = val[q], c = ecol[q];
-    if (v < 0 || v == c) return;
-    int cls = 31 - __clz(v ^ c);
-    int64_t cell = (int64_t)cls * n1 + c;
-    L[G[cell] + atomicAdd(&fill[cell], 1)] = v;             // (order inside a cell is irrelevant: only counts are taken)
 }
 
 // ------------------------------------------------------------------ the last row n in the planes above its lowest bit
@@ -367,9 +335,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
                                                       unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
-                                                      int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0,
-                                                      const int32_t *__restrict__ rcG, const int32_t *__restrict__ rcL, const int32_t *__restrict__ rcH,
-                                                      const int32_t *__restrict__ rcG2, const int32_t *__restrict__ rcL2, const int32_t *__restrict__ rcH2)
+                                                      int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -391,23 +357,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             int64_t rb = (r >> b) << b;
             int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau);
             B = opt[(int64_t)b * n1 + PR(rL)];
-            int32_t crv, crv2 = 0;
-            if (rcG) {                                  // right part from the class lists: table + the class-b entries below B
-                const int64_t cell = (int64_t)b * n1;
-                int32_t e = 0;
-                for (int32_t i = rcG[cell + rL], i1 = rcG[cell + r]; i < i1; i++) e += (rcL[i] < (int32_t)B);
-                crv = rcH[cell + PR(r)] + e;
-                if (HYP) {
-                    int32_t e2 = 0;
-                    for (int32_t i = rcG2[cell + rL], i1 = rcG2[cell + r]; i < i1; i++) e2 += (rcL2[i] >= (int32_t)B);
-                    crv2 = rcH2[cell + PR(r)] + e2;
-                }
-            } else {
-                crv = cr[(int64_t)b * n1 + PR(r)];
-                if (HYP) crv2 = crl[(int64_t)b * n1 + PR(r)];
-            }
-            S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + crv;
-            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crv2;
+            S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
+            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
             // left end of the range: the winner of the right neighbour -- or, where that lies beyond the matrix, of the last
             // row n (same rectangle; known since round A); the block start for the last row of a rectangle
             a = (rR - rb) < ((int64_t)1 << b) ? (int64_t)opt[(int64_t)b * n1 + PR(rR <= R.n ? rR : R.n)] : rb - ((int64_t)1 << b);
@@ -1767,9 +1718,6 @@ struct LayerWork {
     DBuf<int32_t> o_rlen, o_ntl, o_tS0l, o_task, o_tileS, o_tileS2, o_wide, o_hi;
     DBuf<Best<TC, true>> o_sub;                         // gap passes: segment winners of the tiles with specials, [tile][SMAX + 1]
     DBuf<int32_t> o_spv;                                // ... and the specials between them
-    // right parts from class lists (rounds tau <= rc_tau): cell pointers, values, always-counted table; [1]: the ge lists
-    bool rc_built = false; int rc_tau = -1;
-    DBuf<int32_t> rc_G[2], rc_L[2], rc_H[2];
     // round A from cached counts
     bool ra_built = false; RATab ra_tab; int64_t ra_ntile = 0, ra_nrow = 0;
     DBuf<int32_t> ra_c, ra_c2;
@@ -1889,36 +1837,6 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     }
 }
 
-// builds the class lists of the right parts (once per partition)
-template <typename TC>
-static void rc_build(cp_csr_s *A, LayerWork<TC> &Wk, int rc_tau)
-{
-    hipStream_t s = A->stream;
-    const int64_t n = A->n, n1 = n + 1;
-    const int nbits = Wk.nbits;
-    const size_t cells = (size_t)nbits * (size_t)n1;
-    for (int which = 0; which < (Wk.hyp ? 2 : 1); which++) {
-        const int64_t Ne = which ? A->nrows_nonempty : A->N;
-        const int32_t *val = which ? A->lfirst.p : A->prev.p, *ecol = which ? A->llast.p : A->col.p;
-        int32_t *cnt = which ? Wk.crl.p : Wk.cr.p;          // (the right-part plane array of the rounds: free now, same size)
-        Wk.rc_G[which].ensure(cells + 1); Wk.rc_L[which].ensure((size_t)(Ne > 0 ? Ne : 1)); Wk.rc_H[which].ensure(cells);
-        CP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * cells, s));
-        if (Ne > 0) hipLaunchKernelGGL(k_rc_count, dim3((unsigned)cdiv(Ne, 256)), dim3(256), 0, s, Ne, n1, val, ecol, cnt);
-        exclusive_scan_i32_i32(cnt, Wk.rc_G[which].p, (int64_t)cells, Wk.scratch, s);
-        CP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * cells, s));
-        if (Ne > 0) hipLaunchKernelGGL(k_rc_scatter, dim3((unsigned)cdiv(Ne, 256)), dim3(256), 0, s, Ne, n1, val, ecol, Wk.rc_G[which].p, cnt, Wk.rc_L[which].p);
-        // the always-counted table: the right-part pass itself with the block starts (ends) as thresholds
-        CP_HIP(hipMemsetAsync(Wk.rc_H[which].p, 0, sizeof(int32_t) * cells, s));
-        for (int tau = 0; tau <= rc_tau && tau < nbits; tau++) {
-            RoundDesc R; make_round(R, false, tau, nbits, n, 0, n);
-            if (R.ntask <= 0) continue;
-            launch_rpass(s, R, nbits, n, 0, n, which ? A->lpos.p : A->pos.p, val, which, (const int32_t *)nullptr, Wk.rc_H[which].p);
-        }
-    }
-    CP_HIP(hipGetLastError());
-    Wk.rc_built = true; Wk.rc_tau = rc_tau;
-}
-
 // builds the cached round-A counts (once per partition: they depend on the pattern only)
 template <typename TC>
 static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
@@ -2013,11 +1931,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         }
         if (R.ntask <= 0) continue;
         RoundCounts *rc = Wk.rc.p + rd;
-        const int rc_tau = (int)std::min<int64_t>(g_opt_rc_tau, 9);       // (above: chunked right-part passes with atomics)
-        const bool rcl = !R.isA && R.tau <= rc_tau;                       // right parts of this round from the class lists
-        if (rcl && (!Wk.rc_built || Wk.rc_tau != rc_tau)) { ProfScope ps(PROF_LINKS, s, 0.0); rc_build<TC>(A, Wk, rc_tau); }
         const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
-        if (!R.isA && !rcl) {
+        if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
             if (((int64_t)1 << R.tau) > g_opt_rpass_ch)   // several chunks per row accumulate with atomics: clear first
@@ -2039,8 +1954,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
-                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p,                                       \
-                rcl ? Wk.rc_G[0].p : (const int32_t *)nullptr, Wk.rc_L[0].p, Wk.rc_H[0].p, Wk.rc_G[1].p, Wk.rc_L[1].p, Wk.rc_H[1].p
+                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
@@ -2273,7 +2187,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     while (((int64_t)1 << nbits) <= n) nbits++;
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
-        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.rc_built = false;
+        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false;
         Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
@@ -2304,7 +2218,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
-template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->rc_built = false; W->pred_ok = false; }
+template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; }
 template <typename TC> void *dp_total_work_get(cp_csr_s *A)
 {
     const int i = sizeof(TC) == sizeof(double) && ((TC)0.5 != (TC)0) ? 1 : 0;

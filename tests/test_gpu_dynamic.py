@@ -138,11 +138,10 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
 #   gap_min    shortest task taken by a gap pass
 #   ra_cache   round A from counts computed once per partition / recomputed by every layer
 #   dbg 512    every gap tile takes the entry-by-entry path (as if it held too many specials)
-#   rc_tau     rounds tau <= rc_tau take their right parts from the class lists (-1: right-part passes everywhere)
 LAYER_OPTIONS = [{"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 0}, {"gap_tau": 3, "gap_min": 8}, {"gap_tau": 8, "gap_min": 16}, {"gap_tau": 12},
                  {"ra_cache": 0}, {"ra_cache": 0, "gap_tau": -1, "nospec": 1}, {"dbg": 512}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
-                 {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rc_tau": 5}, {"rc_tau": 0}, {"rc_tau": 9}, {"rc_tau": 3, "rpass_ch": 16, "gap_tau": -1}]
-LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 5, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 3, "rpass_ch": 512, "rc_tau": -1}
+                 {"rpass_small_tau": 6}, {"rpass_ch": 16}]
+LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 5, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 3, "rpass_ch": 512}
 
 
 @pytest.mark.parametrize("oi", range(len(LAYER_OPTIONS)))
