@@ -161,7 +161,13 @@ int32_t cp_dp_destroy(cp_dp_t dp);
 /* ---- execution control / measurement ---- */
 /* run subsequent launches of this csr on an existing hipStream_t (e.g. torch's current stream) */
 int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
-/* force the general O(K n^2) device DP even where the O(K n log^2 n) path applies (tests) */
+/* Library-wide tunables and test switches; results never depend on them (tests/test_gpu_dynamic.py runs every one against the
+ * oracle).  "force_brute" 1: the general O(K n^2) device DP even where the O(K n log^2 n) scheme applies; "brute_max_n": its size
+ * limit.  Layer driver of the O(K n log^2 n) scheme: "short_t"/"short_e" (tasks finished during setup),
+ * "own_min" (shortest task with tiles of its own), "gap_tau"/"gap_min" (gap passes: rounds and task lengths; -1: none),
+ * "ra_cache" (round A from counts cached per partition), "nospec" 1 (one host sync per round instead of sizing a layer from the
+ * previous one), "rpass_ch"/"rpass_small_tau" (right-part passes), "prof_only" slot (events on one profile slot only), "dbg"
+ * (diagnostic bit mask).  Unknown names return CP_EINVAL. */
 int32_t cp_set_option(const char *name, int64_t value);
 /* built-in per-kernel HIP-event timing of the named hot kernels on the launch stream */
 int32_t cp_prof_enable(int32_t on);
