@@ -1962,6 +1962,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundCounts P;                                   // the counts this round is sized with
         if (spec) {
             P = Wk.pred[(size_t)rd];
+            if ((g_opt_dbg & 1024) && (rd & 1)) { P.nown = 0; P.NT = 0; P.nlong = 0; P.T = 0; }      // test: a prediction that skips stages with work
             // buffers from the prediction (grown only here; k_round_finish checks the true totals against them)
             Wk.ensure_own((size_t)grow(P.NT));
             Wk.ensure_flat((size_t)grow(P.T));
@@ -1978,7 +1979,9 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     if (nm <= LB_MAX) exclusive_scan_i32_lb(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, nm, &rc->NT, Wk.scanws, s);
                     else exclusive_scan_i32_devn(Wk.o_ntl.p, Wk.o_toffs.p, &rc->nown, nm, &rc->NT, Wk.scratch, s);
                 }
-            hipLaunchKernelGGL(k_round_finish, dim3(1), dim3(1), 0, s, rc, spec ? (int64_t)Wk.loc.n : INT64_MAX, spec ? (int64_t)Wk.o_rec.n : INT64_MAX);
+            const bool tiny = spec && (g_opt_dbg & 2048);       // test: pretend the buffers sized from the prediction are too small
+            hipLaunchKernelGGL(k_round_finish, dim3(1), dim3(1), 0, s, rc, spec ? (tiny ? (int64_t)64 : (int64_t)Wk.loc.n) : INT64_MAX,
+                               spec ? (tiny ? (int64_t)1 : (int64_t)Wk.o_rec.n) : INT64_MAX);
         }
         if (!spec) {
             CP_HIP(hipMemcpyAsync(&P, rc, sizeof(P), hipMemcpyDeviceToHost, s));
