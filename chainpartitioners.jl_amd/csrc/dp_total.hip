@@ -814,13 +814,20 @@ __device__ __forceinline__ int32_t gap_right_counts(const int32_t *__restrict__ 
     if (cl > n) cl = n;
     const int32_t myend = cpos[jn], e0 = cpos[cfirst], e1 = cpos[cl];
     int32_t mine = 0;
-    for (int32_t base = e0; base < e1; base += 64) {
-        int32_t q = base + lane;
-        bool fl = false;
-        if (q < e1) { int32_t v = arr[q]; fl = GE ? (v >= thr) : (v < thr); }
-        unsigned long long m = __ballot(fl);
-        int32_t w = myend - base;
-        if (w > 0) mine += __popcll(w >= 64 ? m : (m & ((1ull << w) - 1ull)));
+    for (int32_t base = e0; base < e1; base += 256) {       // four loads in flight
+        bool fl[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int32_t q = base + 64 * j + lane;
+            fl[j] = false;
+            if (q < e1) { int32_t v = arr[q]; fl[j] = GE ? (v >= thr) : (v < thr); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned long long m = __ballot(fl[j]);
+            int32_t w = myend - (base + 64 * j);
+            if (w > 0) mine += __popcll(w >= 64 ? m : (m & ((1ull << w) - 1ull)));
+        }
     }
     return c + mine;
 }
@@ -832,6 +839,14 @@ struct GapCtx {
     const int32_t *pos, *next, *fpos, *flast;
     const TC *W;
 };
+
+// wave-uniform lane index: one v_readlane instead of a ds_bpermute
+__device__ __forceinline__ int32_t rdl(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int64_t rdl64(int64_t v, int src)
+{
+    return ((int64_t)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
+}
+__device__ __forceinline__ double rdl64(double v, int src) { return __longlong_as_double((long long)rdl64((int64_t)__double_as_longlong(v), src)); }
 
 // the tiles [ka, kz) of a task (first tile k0, head B, L steps, row r) walked for the 64 rows of the wave: the winners so far
 // (bv, bp, bl, bl2) and the specials the rows count so far (cum, cum2) are carried in and out
@@ -848,31 +863,42 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
     Best<TC, HYP> m_part; best_clear(m_part);
     if (m_ns == 0) m_part = C.part[km];
     const int nb = (int)(kz - kb < 64 ? kz - kb : 64);
+    // the segment records of the NEXT tile are fetched while the current tile is walked (the walk is a chain of dependent loads)
+    Best<TC, HYP> nx_c; best_clear(nx_c);
+    int32_t nx_sv = 0;
+    {
+        const int ns0 = rdl(m_ns, 0);
+        if (ns0 > 0 && ns0 <= SMAX) { if (lane <= ns0) nx_c = C.sub[kb * (SMAX + 1) + lane]; if (lane < ns0) nx_sv = C.spv[kb * (SMAX + 1) + lane]; }
+    }
     for (int i = 0; i < nb; i++) {
         const int64_t k = kb + i;
-        const int32_t base = __shfl(m_base, i), base2 = HYP ? __shfl(m_base2, i) : 0;
-        const int ns = __shfl(m_ns, i);
+        const int32_t base = rdl(m_base, i), base2 = HYP ? rdl(m_base2, i) : 0;
+        const int ns = rdl(m_ns, i);
+        const Best<TC, HYP> cur_c = nx_c;
+        const int32_t cur_sv = nx_sv;
+        if (i + 1 < nb) {
+            const int ns1 = rdl(m_ns, i + 1);
+            if (ns1 > 0 && ns1 <= SMAX) { if (lane <= ns1) nx_c = C.sub[(k + 1) * (SMAX + 1) + lane]; if (lane < ns1) nx_sv = C.spv[(k + 1) * (SMAX + 1) + lane]; }
+        }
         if (ns <= SMAX) {
             // plain tile: one winner; tile with ns specials: ns + 1 segment winners, a special between two segments
-            Best<TC, HYP> c; best_clear(c);
-            int32_t sv = 0;
+            Best<TC, HYP> c = cur_c;
+            int32_t sv = cur_sv;
             if (ns == 0) {
-                c.v = shfl64(m_part.v, i); c.p = __shfl(m_part.p, i); c.nn = __shfl(m_part.nn, i);
-                if (HYP) best_set_nl(c, __shfl(best_nl(m_part), i));
-            } else {
-                if (lane <= ns) c = C.sub[k * (SMAX + 1) + lane];
-                if (lane < ns) sv = C.spv[k * (SMAX + 1) + lane];
+                best_clear(c);
+                c.v = rdl64(m_part.v, i); c.p = rdl(m_part.p, i); c.nn = rdl(m_part.nn, i);
+                if (HYP) best_set_nl(c, rdl(best_nl(m_part), i));
             }
             for (int sg = 0; sg <= ns; sg++) {
                 Best<TC, HYP> d = c;
-                if (ns) { d.v = shfl64(c.v, sg); d.p = __shfl(c.p, sg); d.nn = __shfl(c.nn, sg); if (HYP) best_set_nl(d, __shfl(best_nl(c), sg)); }
+                if (ns) { d.v = rdl64(c.v, sg); d.p = rdl(c.p, sg); d.nn = rdl(c.nn, sg); if (HYP) best_set_nl(d, rdl(best_nl(c), sg)); }
                 if (d.p >= 0) {
                     int32_t lc = d.nn + base + cum, lc2 = HYP ? best_nl(d) + base2 + cum2 : 0;
                     TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum), (int64_t)(base2 + cum2)));
                     if (bp < 0 || v < bv) { bv = v; bp = d.p; bl = lc; bl2 = lc2; }
                 }
                 if (sg < ns) {                          // the candidates from here on have this special on their right
-                    const int32_t s1 = __shfl(sv, sg), val = s1 & 0x7fffffff;
+                    const int32_t s1 = rdl(sv, sg), val = s1 & 0x7fffffff;
                     if (s1 >= 0) cum += (val >= rcmp);
                     else cum2 += (valid && val < rr);
                 }
