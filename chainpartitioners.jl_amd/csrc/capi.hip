@@ -124,6 +124,19 @@ template <typename TC> static TC host_alpha(const cp_model_t *m, int64_t k)
     return model_param<TC>(m, CP_P_ALPHA);
 }
 
+// diff[0] |= "the two cost rows differ somewhere" (bitwise comparison: the tables are compared, not the values' meaning)
+template <typename TC>
+__global__ void __launch_bounds__(256) k_rows_differ(const TC *__restrict__ a, const TC *__restrict__ b, int64_t n1, int32_t *__restrict__ diff)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool d = false;
+    if (i < n1) {
+        static_assert(sizeof(TC) == 8, "cost rows are 8-byte elements");
+        d = reinterpret_cast<const unsigned long long *>(a)[i] != reinterpret_cast<const unsigned long long *>(b)[i];
+    }
+    if (__ballot(d) && (threadIdx.x & 63) == 0) atomicOr(diff, 1);
+}
+
 // ------------------------------------------------------------------ the K-part DP driver (unconstrained)
 template <typename TC>
 static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, const cp_model_t *mdl,
@@ -172,12 +185,33 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     dump_layer(1, cstA.p, false);
     void *work = fast ? dp_total_work_get<TC>(A) : nullptr;       // (kept in the handle between calls)
     TC *prevc = cstA.p, *curc = cstB.p;
+    // cp_set_option("fixed_point", 1) -- OFF by default: a layer is a function of the previous layer's cost row alone (the model
+    // does not depend on k unless per-part alphas are given), so once a full layer reproduces its input row bit for bit every
+    // later layer repeats it: its argmin row is copied instead of recomputed.  Exact, but it turns K layers into two for
+    // costs where empty parts are free (alpha = 0): a property of the input, kept out of the default so that timings mean
+    // "K layers computed".
+    const bool fp_ok = g_opt_fixed_point && !(order == CP_ORDER_SPLITTER && mdl->alpha_k && mdl->n_alpha_k > 0);
+    DBuf<int32_t> diff(1);
     for (int64_t k = 2; k <= K; k++) {
         int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
         bool last = (k == K);
         if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work, last ? n : 0, n);   // layer K: row n+1 only (:34)
         else dp_brute_layer<TC>(A, HM.d, alpha_of(k), combine, prevc, curc, pk, last ? n : 0, n);   // layer K: row n+1 only (:34)
         dump_layer(k, curc, last);
+        if (fp_ok && !last) {
+            int32_t hd = 1;
+            CP_HIP(hipMemsetAsync(diff.p, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_differ<TC>), dim3((unsigned)cdiv((int64_t)n1, 256)), dim3(256), 0, s, prevc, curc, (int64_t)n1, diff.p);
+            CP_HIP(hipMemcpyAsync(&hd, diff.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            CP_HIP(hipStreamSynchronize(s));
+            if (!hd) {                               // fixed point: layers k+1 .. K repeat layer k
+                for (int64_t k2 = k + 1; k2 <= K; k2++) {
+                    CP_HIP(hipMemcpyAsync(ptr.p + (size_t)(k2 - 1) * n1, pk, sizeof(int32_t) * n1, hipMemcpyDeviceToDevice, s));
+                    dump_layer(k2, curc, k2 == K);
+                }
+                break;
+            }
+        }
         std::swap(prevc, curc);
     }
     // unravel_splits (DynamicSplitter.jl:89-99): K dependent single-element reads of ptr
@@ -445,6 +479,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "rpass_small_tau")) { g_opt_rpass_small_tau = value; return CP_OK; }
+    if (!strcmp(name, "fixed_point")) { g_opt_fixed_point = value; return CP_OK; }
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     set_error("unknown option");

@@ -41,6 +41,7 @@ bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, T
 
 extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <= gap_tau (-1: none) for tasks of >= gap_min candidates
 extern int64_t g_opt_ra_cache;                 // 1: round A from counts computed once per partition
+extern int64_t g_opt_fixed_point;              // 1: layers after a layer that reproduced its input row are copied (run_dynamic)
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
 extern int64_t g_opt_rpass_small_tau;           // rounds tau <= this use one lane per row in the right-part pass

@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int4 *__restrict__ o_tdesc, uint8_t *__restrict__ o_tb, int32_t *__restrict__ o_rlen,
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
                                                       unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
-                                                      int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0)
+                                                      int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0,
+                                                      int32_t *__restrict__ dbg_ntriv)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -365,6 +366,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
         }
         int64_t L = 1 + (B - a);
+        if (dbg_ntriv && L > 1 && !R.isA) atomicAdd(dbg_ntriv, 1);
         bool is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
         if (is_short) {
             int64_t rw = (int64_t)b * n1 + PR(r);
@@ -1980,7 +1982,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
-                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p
+                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr
             if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
             else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
@@ -2016,8 +2018,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             Wk.ensure_flat((size_t)P.T);
         }
         used[(size_t)rd] = P;
-        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld %s long=%d own=%d T=%lld NT=%lld\n", R.isA, R.tau, (long long)R.ntask,
-                                   spec ? "predicted" : "exact", P.nlong, P.nown, (long long)P.T, (long long)P.NT);
+        if (g_opt_dbg & 8) fprintf(stderr, "round isA=%d tau=%d ntask=%lld %s long=%d own=%d T=%lld NT=%lld nontrivial=%d\n", R.isA, R.tau, (long long)R.ntask,
+                                   spec ? "predicted" : "exact", P.nlong, P.nown, (long long)P.T, (long long)P.NT, P._pad);
         if (P.nown > 0 && P.NT > 0) {
             // ---- long tasks with tiles of their own: map, stream + evaluate, merge
             const int64_t gNT = spec ? (int64_t)Wk.o_rec.n : P.NT, gown = spec ? grow(P.nown) : P.nown;      // (capacity >= the true NT, checked)
