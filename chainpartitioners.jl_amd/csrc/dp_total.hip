@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
     bool live = t < R.ntask;
-    bool is_long = false, is_own = false;
+    bool is_long = false, is_own = false, is_short = false;
     int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
     if (live) {
         decode_task(R, t, r, b);
@@ -367,28 +367,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         }
         int64_t L = 1 + (B - a);
         if (dbg_ntriv && L > 1 && !R.isA) atomicAdd(dbg_ntriv, 1);
-        bool is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
+        is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
         if (is_short) {
-            int64_t rw = (int64_t)b * n1 + PR(r);
-            if (L == 1 && !R.isA) {                  // one candidate: nothing to compare
-                opt[rw] = (int32_t)B; nnopt[rw] = (int32_t)S0; if (HYP) nlopt[rw] = (int32_t)S0l;
-            } else {
-                int32_t rr = (int32_t)r, posr = pos32[r];
-                int64_t nn = S0, nl = S0l;
-                Best<TC, HYP> best; best_clear(best);
-                for (int64_t i = 0; i < L; i++) {    // decreasing p: an earlier candidate wins ties
-                    int64_t p = B - i;
-                    if (i > 0) {
-                        for (int32_t q = pos32[p]; q < pos32[p + 1]; q++) nn += (next[q] >= rr);
-                        if (HYP) for (int32_t q = fpos32[p]; q < fpos32[p + 1]; q++) nl += (flast[q] < rr);
-                    }
-                    if (i == 0 && R.isA) continue;   // round A: p = r is not a candidate
-                    TC fv = dm_apply(M, alpha, r - p, (int64_t)(posr - pos32[p]), nn, nl);
-                    Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
-                    best = better(best, c);
-                }
-                opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
-            }
         } else if (o_tdesc && L >= OWN_MIN) {
             is_own = true;                           // long enough for tiles of its own (k_lpass_own): every tile is uniform
         } else {
@@ -430,12 +410,37 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     }
     if (is_own) {
         int32_t idx = s_base[1] + s_wcnt[1][wv] + __popcll(mo & ((1ull << lane) - 1ull));
-        if (idx >= o_cap) { *err = 1; return; }          // cannot happen (LayerWork sizes the list for the worst case); never write outside
+        if (idx >= o_cap) { *err = 1; return; }          // (an own task is never short) cannot happen (LayerWork sizes the list for the worst case); never write outside
         o_tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
         o_tb[idx] = (uint8_t)b;
         o_rlen[idx] = (int32_t)Lmine;
         o_ntl[idx] = (int32_t)((Lmine + LT - 1) / LT);
         if (HYP) o_tS0l[idx] = (int32_t)S0l;
+    }
+    // the short tasks are finished by their lanes -- AFTER the barriers above, so that no wave of the block waits for the lane with
+    // the longest walk
+    if (is_short) {
+        const int64_t n1 = R.n + 1, L = 1 + (B - a);
+        int64_t rw = (int64_t)b * n1 + PR(r);
+        if (L == 1 && !R.isA) {                  // one candidate: nothing to compare
+            opt[rw] = (int32_t)B; nnopt[rw] = (int32_t)S0; if (HYP) nlopt[rw] = (int32_t)S0l;
+        } else {
+            int32_t rr = (int32_t)r, posr = pos32[r];
+            int64_t nn = S0, nl = S0l;
+            Best<TC, HYP> best; best_clear(best);
+            for (int64_t i = 0; i < L; i++) {    // decreasing p: an earlier candidate wins ties
+                int64_t p = B - i;
+                if (i > 0) {
+                    for (int32_t q = pos32[p]; q < pos32[p + 1]; q++) nn += (next[q] >= rr);
+                    if (HYP) for (int32_t q = fpos32[p]; q < fpos32[p + 1]; q++) nl += (flast[q] < rr);
+                }
+                if (i == 0 && R.isA) continue;   // round A: p = r is not a candidate
+                TC fv = dm_apply(M, alpha, r - p, (int64_t)(posr - pos32[p]), nn, nl);
+                Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
+                best = better(best, c);
+            }
+            opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
+        }
     }
 }
 
