@@ -578,7 +578,6 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
     for (int k = 0; k < 4; k++) { int32_t e = lane + 64 * k; sk[k] = e <= tl ? cpos[p_first - e] : INT32_MAX; acc[k] = 0; }
     // head != 0: step 0 is the candidate p_first itself (no column stepped over): the run ends in front of that column
     int32_t Q_hi = cpos[p_first + 1 - head], Q_lo = cpos[p_first - tl];       // wave-uniform
-    unsigned long long below = (1ull << lane) - 1ull;
     int32_t x = Q_lo & ~3;
     int4 c0 = make_int4(FILL, FILL, FILL, FILL), c1 = c0;
     if (x + 4 * lane < Q_hi) c0 = *reinterpret_cast<const int4 *>(arr + x + 4 * lane);          // arrays are padded by 8 entries
@@ -594,11 +593,10 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
             int4 v = c ? c1 : c0;
             int32_t pb = xc + 4 * lane;
             // entries at or above Q_hi belong to columns above the tile: never flagged (those below Q_lo lie below every s)
-            unsigned long long m0, m1, m2, m3;
-            if (GE) { m0 = __ballot(pb < Q_hi && v.x >= thr); m1 = __ballot(pb + 1 < Q_hi && v.y >= thr);
-                      m2 = __ballot(pb + 2 < Q_hi && v.z >= thr); m3 = __ballot(pb + 3 < Q_hi && v.w >= thr); }
-            else    { m0 = __ballot(pb < Q_hi && v.x < thr); m1 = __ballot(pb + 1 < Q_hi && v.y < thr);
-                      m2 = __ballot(pb + 2 < Q_hi && v.z < thr); m3 = __ballot(pb + 3 < Q_hi && v.w < thr); }
+            // the lane's four flags, and the four wave masks
+            const bool f0 = pb < Q_hi && (GE ? v.x >= thr : v.x < thr), f1 = pb + 1 < Q_hi && (GE ? v.y >= thr : v.y < thr);
+            const bool f2 = pb + 2 < Q_hi && (GE ? v.z >= thr : v.z < thr), f3 = pb + 3 < Q_hi && (GE ? v.w >= thr : v.w < thr);
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
             if (DET) {
                 const uint32_t span = (uint32_t)(sp_hi - sp_lo - 1);           // v in (sp_lo, sp_hi)  <=>  (uint)(v - sp_lo - 1) < span
                 bool s0 = pb >= Q_lo && pb < Q_hi && (uint32_t)(v.x - sp_lo - 1) < span, s1 = pb + 1 >= Q_lo && pb + 1 < Q_hi && (uint32_t)(v.y - sp_lo - 1) < span;
@@ -618,7 +616,14 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
                 }
             }
             int32_t tot = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);                       // uniform
-            int32_t P0 = __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+            // flagged entries in the lanes below this one (v_mbcnt chains), packed with the lane's own first three flags: one
+            // cross-lane read then gives a step everything it needs about the lane its column starts in
+            uint32_t P0 = 0;
+            P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, P0));
+            P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, P0));
+            P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, P0));
+            P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, P0));
+            const int32_t pack = (int32_t)((P0 << 3) | (uint32_t)f0 | ((uint32_t)f1 << 1) | ((uint32_t)f2 << 2));
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int32_t idx = sk[k] - xc;                 // block position of the step's first entry (huge for invalid steps)
@@ -626,9 +631,8 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
                 if (__ballot(inside)) {                   // wave-uniform: some column of this group starts inside the block
                     int32_t cidx = inside ? idx : 0;
                     int src = cidx >> 2, comp = cidx & 3;
-                    int32_t Ps = __shfl(P0, src);
-                    uint32_t bits = (uint32_t)((m0 >> src) & 1ull) | ((uint32_t)((m1 >> src) & 1ull) << 1) | ((uint32_t)((m2 >> src) & 1ull) << 2);
-                    int32_t Fb = Ps + __popc(bits & ((1u << comp) - 1u));        // flagged entries of the block below position idx
+                    const int32_t g = __shfl(pack, src);
+                    int32_t Fb = (g >> 3) + __popc((uint32_t)g & ((1u << comp) - 1u));        // flagged entries of the block below position idx
                     acc[k] += idx <= 0 ? tot : (inside ? tot - Fb : 0);
                 } else {
                     acc[k] += idx <= 0 ? tot : 0;
