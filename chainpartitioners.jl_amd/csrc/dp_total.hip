@@ -34,6 +34,18 @@
 
 namespace cpk {
 
+// The O(n log^2 n) scheme only admits the affine Work / Connectivity / HyperedgeCut models (fast_total_ok): its kernels evaluate
+// costs through this three-way form, so the block-cost tables and pow() of the general dm_apply stay out of their registers.
+template <typename TC>
+__device__ __forceinline__ TC dm_apply_affine(const DevModel<TC> &m, TC alpha, int64_t nv, int64_t np, int64_t nn, int64_t nl)
+{
+    TC v = cadd(cadd(alpha, cmulc(nv, m.p[CP_P_VERTEX])), cmulc(np, m.p[CP_P_PIN]));       // (left to right, as the reference sums)
+    if (m.kind == CP_MODEL_CONNECTIVITY) return cadd(v, cmulc(nn, m.p[CP_P_NET]));
+    if (m.kind == CP_MODEL_HYPEREDGE_CUT) return cadd(cadd(v, cmulc(nl, m.p[CP_P_SELF_NET])), cmulc(nn - nl, m.p[CP_P_CUT_NET]));
+    return v;
+}
+#define dm_apply dm_apply_affine
+
 constexpr int LT = 256;          // steps per tile (one wave owns one tile)
 constexpr int NBMAX = 31;        // bit planes (n < 2^30)
 
