@@ -350,14 +350,27 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0,
                                                       int32_t *__restrict__ dbg_ntriv)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
-    bool live = t < R.ntask;
+    bool live;
     bool is_long = false, is_own = false, is_short = false;
     int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
-    if (live) {
-        decode_task(R, t, r, b);
-        if (fin && !R.isA && fin[(int64_t)b * (R.n + 1) + prow(r, R.n)]) live = false;      // finished by a gap pass of an earlier round
+    if (R.isA) {
+        int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        live = t < R.ntask;
+        if (live) decode_task(R, t, r, b);
+    } else {
+        // tau rounds: blockIdx.y is the bit plane (no per-thread search for it), blockIdx.x * 1024 + thread the task inside the plane
+        b = R.tau + 1 + (int)blockIdx.y;
+        int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        live = l < R.tbase[b + 1] - R.tbase[b];
+        if (live) {
+            l += R.tskip[b];
+            int sh = b - R.tau - 1;
+            int64_t base = l >> sh, v = l & (((int64_t)1 << sh) - 1);
+            r = (base << (b + 1)) | ((int64_t)1 << b) | (((v << 1) | 1) << R.tau);
+            // (rows of a tau round have ctz == tau: their plane slot needs no bit search)
+            if (fin && fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))]) live = false;      // finished by a gap pass of an earlier round
+        }
     }
     if (live) {
         int64_t n1 = R.n + 1;
@@ -2004,8 +2017,14 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
                 (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), dim3((unsigned)cdiv(R.ntask, 1024)), dim3(1024), 0, s, SS_ARGS);
+            dim3 sgrid((unsigned)cdiv(R.ntask, 1024));
+            if (!R.isA) {                                // one grid row per bit plane above tau
+                int64_t mx = 1;
+                for (int bb = R.tau + 1; bb < nbits; bb++) mx = std::max<int64_t>(mx, R.tbase[bb + 1] - R.tbase[bb]);
+                sgrid = dim3((unsigned)cdiv(mx, 1024), (unsigned)std::max(1, nbits - R.tau - 1));
+            }
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), sgrid, dim3(1024), 0, s, SS_ARGS);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), sgrid, dim3(1024), 0, s, SS_ARGS);
 #undef SS_ARGS
         }
         RoundCounts P;                                   // the counts this round is sized with
