@@ -138,13 +138,18 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
     if (!live) return;
     int64_t q0 = pos[rL], q1 = pos[r];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
-    for (int64_t q = q0; q < q1; q += 4) {                     // four independent loads in flight per lane
-        int32_t v0 = prev[q], v1 = q + 1 < q1 ? prev[q + 1] : NEVER, v2 = q + 2 < q1 ? prev[q + 2] : NEVER, v3 = q + 3 < q1 ? prev[q + 3] : NEVER;
+    for (int64_t q = q0; q < q1; q += 16) {                    // sixteen independent loads in flight per lane
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = q + j < q1 ? prev[q + j] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
             if (!((used >> b) & 1)) continue;                  // wave-uniform
             int32_t t = thr[b];
-            cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
+            int32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) c += ge ? (v[j] >= t) : (v[j] < t);
+            cnt[b] += c;
         }
     }
 #pragma unroll
@@ -182,7 +187,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     }
     int64_t q0 = pos[c0], q1 = pos[c1];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
-    for (int64_t q = q0 + lane; q < q1; q += 256) {            // four independent coalesced loads in flight
+    for (int64_t q = q0 + lane; q < q1; q += 256) {            // four independent coalesced loads in flight (eight: no faster)
         int32_t v0 = prev[q], v1 = q + 64 < q1 ? prev[q + 64] : NEVER, v2 = q + 128 < q1 ? prev[q + 128] : NEVER,
                 v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
 #pragma unroll
