@@ -461,7 +461,10 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             for (int64_t i = 0; i < L; i++) {    // decreasing p: an earlier candidate wins ties
                 int64_t p = B - i;
                 if (i > 0) {
-                    for (int32_t q = pos32[p]; q < pos32[p + 1]; q++) nn += (next[q] >= rr);
+                    for (int32_t q = pos32[p], q1 = pos32[p + 1]; q < q1; q += 4) {      // four loads in flight
+                        int32_t v0 = next[q], v1 = q + 1 < q1 ? next[q + 1] : -1, v2 = q + 2 < q1 ? next[q + 2] : -1, v3 = q + 3 < q1 ? next[q + 3] : -1;
+                        nn += (v0 >= rr) + (v1 >= rr) + (v2 >= rr) + (v3 >= rr);
+                    }
                     if (HYP) for (int32_t q = fpos32[p]; q < fpos32[p + 1]; q++) nl += (flast[q] < rr);
                 }
                 if (i == 0 && R.isA) continue;   // round A: p = r is not a candidate
