@@ -563,23 +563,24 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
                 while (rem) {                             // one pass per distinct threshold touching the block
                     int l = __ffsll((long long)rem) - 1;
                     int32_t tu = __shfl(thr, l);
-                    unsigned long long m0, m1, m2, m3;
-                    if (GE) { m0 = __ballot(v.x >= tu); m1 = __ballot(v.y >= tu); m2 = __ballot(v.z >= tu); m3 = __ballot(v.w >= tu); }
-                    else    { m0 = __ballot(v.x < tu);  m1 = __ballot(v.y < tu);  m2 = __ballot(v.z < tu);  m3 = __ballot(v.w < tu); }
+                    const bool f0 = GE ? v.x >= tu : v.x < tu, f1 = GE ? v.y >= tu : v.y < tu, f2 = GE ? v.z >= tu : v.z < tu, f3 = GE ? v.w >= tu : v.w < tu;
+                    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+                    // F(x) = flagged entries at block positions < x = (flags in the lanes below lane x/4) + (flags of that lane below
+                    // component x%4): the lane-below counts come from v_mbcnt chains, packed with the lane's own flags, and a lane
+                    // takes  F(a1) - F(a0)  for its range [a0, a1) with two cross-lane reads
+                    uint32_t P0 = 0;
+                    P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, P0));
+                    P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, P0));
+                    P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, P0));
+                    P0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, P0));
+                    const int32_t pack = (int32_t)((P0 << 3) | (uint32_t)f0 | ((uint32_t)f1 << 1) | ((uint32_t)f2 << 2));
+                    const int32_t tot = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);         // (uniform)
+                    const int32_t g0 = __shfl(pack, (a0 >> 2) & 63), g1 = __shfl(pack, (a1 >> 2) & 63);      // (every lane takes part)
                     bool same = ov && thr == tu;
                     if (same) {
-#define CP_CNT(mj, j)                                                                                   \
-    {                                                                                                   \
-        int lo_ = (a0 - (j) + 3) >> 2, hi_ = (a1 - (j) + 3) >> 2;                                       \
-        if (lo_ < 0) lo_ = 0;                                                                           \
-        if (hi_ > lo_) {                                                                                \
-            int w_ = hi_ - lo_;                                                                         \
-            unsigned long long mm_ = (w_ >= 64) ? ~0ull : (((1ull << w_) - 1) << lo_);                 \
-            d += __popcll((mj) & mm_);                                                                  \
-        }                                                                                               \
-    }
-                        CP_CNT(m0, 0) CP_CNT(m1, 1) CP_CNT(m2, 2) CP_CNT(m3, 3)
-#undef CP_CNT
+                        int32_t F0 = (g0 >> 3) + __popc((uint32_t)g0 & ((1u << (a0 & 3)) - 1u));
+                        int32_t F1 = a1 >= 256 ? tot : (g1 >> 3) + __popc((uint32_t)g1 & ((1u << (a1 & 3)) - 1u));
+                        d += F1 - F0;
                     }
                     rem &= ~__ballot(same);
                 }
