@@ -597,15 +597,14 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // a block is counted); per block: four ballots, a per-lane popcount prefix, and one gather per step whose column starts
 // inside the block.  Lane l owns the steps l, l+64, l+128, l+192.
 // DET (gap passes, see k_gap_finish): the entries of the run with a value strictly between sp_lo and sp_hi ("specials") are
-// appended to the wave's list by the lanes that hold them (LDS counter s_cnt): s_es[i] = first step e whose candidate has the
-// entry's column on its right (steps >= e count it) = p_first - column, s_v[i] = the value, tagged with `kind` in bit 31.
-// ecol: the column of every entry of arr.  Only the first SMAX specials are stored; s_cnt keeps counting.
+// appended to the wave's list by the lanes that hold them (LDS counter s_cnt): s_es[i] = the entry's position (the caller turns it
+// into the first step whose candidate has the entry's column on its right), s_v[i] = the value, tagged with `kind` in bit 31.
+// Only the first SMAX specials are stored; s_cnt keeps counting.
 constexpr int SMAX = 31;
 template <bool GE, bool DET = false>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
                                                 int32_t thr, int lane, int32_t acc[4], int32_t sk[4], int head = 0, int32_t sp_lo = 0, int32_t sp_hi = 0,
-                                                int32_t *s_es = nullptr, int32_t *s_v = nullptr, int32_t *s_cnt = nullptr, int kind = 0,
-                                                const int32_t *__restrict__ ecol = nullptr)
+                                                int32_t *s_es = nullptr, int32_t *s_v = nullptr, int32_t *s_cnt = nullptr, int kind = 0)
 {
     const int32_t FILL = GE ? INT32_MIN : INT32_MAX;      // never flagged
 #pragma unroll
@@ -642,7 +641,7 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
                             int32_t val = j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
                             int slot = atomicAdd(s_cnt, 1);
                             if (slot <= SMAX - 1) {
-                                s_es[slot] = p_first - ecol[pb + j];
+                                s_es[slot] = pb + j;                  // (the position; its column is looked up after the stream: no load stalls the loop)
                                 s_v[slot] = (int32_t)(((uint32_t)val & 0x7fffffffu) | ((uint32_t)kind << 31));
                             }
                         }
@@ -744,11 +743,19 @@ __global__ void __launch_bounds__(256) k_lpass_own(int isA, const RoundCounts *_
         if (lane == 0) *s_cnt = 0;
         __threadfence_block();
         int32_t rL = rec.y - (1 << tau), hi1 = gap_hi[tile] - 1;
-        interior_stream<true, true>(a_next, a_pos, rec.x, tl, hi1, lane, acc, sk, head, rL, hi1, s_es[0], s_v[0], s_cnt, 0, a_col);
-        if (HYP) interior_stream<false, true>(a_flast, a_fpos, rec.x, tl, rL + 1, lane, acc2, sk2, head, rL, hi1, s_es[0], s_v[0], s_cnt, 1, a_ffirst);
+        interior_stream<true, true>(a_next, a_pos, rec.x, tl, hi1, lane, acc, sk, head, rL, hi1, s_es[0], s_v[0], s_cnt, 0);
+        if (HYP) interior_stream<false, true>(a_flast, a_fpos, rec.x, tl, rL + 1, lane, acc2, sk2, head, rL, hi1, s_es[0], s_v[0], s_cnt, 1);
         __threadfence_block();
         ns = *s_cnt;
         if (force_spec) ns = SMAX + 1;
+        if (ns > 0 && ns <= SMAX) {                     // positions -> steps: first step whose candidate has the entry's column on its right
+            if (lane < ns) {
+                const int32_t q = s_es[0][lane];
+                const bool k1 = s_v[0][lane] < 0;       // (bit 31: an entry of the second list)
+                s_es[0][lane] = rec.x - (k1 ? a_ffirst[q] : a_col[q]);
+            }
+            __threadfence_block();
+        }
     } else {
         interior_stream<true>(a_next, a_pos, rec.x, tl, rec.y, lane, acc, sk, head);
         if (HYP) interior_stream<false>(a_flast, a_fpos, rec.x, tl, rec.y, lane, acc2, sk2, head);
