@@ -22,7 +22,7 @@ SYMBOLS = [
     "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
-    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy",
+    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
     "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
 ]
@@ -262,6 +262,26 @@ class HipBackend:
         if rc != 0:
             raise RuntimeError(f"cp_dp_ptr_at -> {rc}: {self.last_error()}")
         return out.value
+
+    def dp_ptr_row(self, dp, k, n):
+        out = np.zeros(n + 1, dtype=np.int64)
+        rc = self.lib.cp_dp_ptr_row(dp, _i64(k), _p(out))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_ptr_row -> {rc}: {self.last_error()}")
+        return out
+
+    def dp_block_tables(self, dp, n, hyper=False):
+        """(nplanes, opt[b, r], nets[b, r], selfnets[b, r] | None) of the last layer computed through `dp`."""
+        nb = C.c_int32()
+        opt = np.zeros((31, n + 1), dtype=np.int64); nn = np.zeros((31, n + 1), dtype=np.int64)
+        nl = np.zeros((31, n + 1), dtype=np.int64) if hyper else None
+        rc = self.lib.cp_dp_block_tables(dp, C.byref(nb), _p(opt), _p(nn), _p(nl))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_block_tables -> {rc}: {self.last_error()}")
+        # the library lays the planes out with stride n+1
+        k = nb.value
+        return k, opt.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), nn.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), \
+            (nl.reshape(-1)[:k * (n + 1)].reshape(k, n + 1) if hyper else None)
 
     def dp_destroy(self, dp):
         self.lib.cp_dp_destroy(dp)

@@ -815,6 +815,45 @@ int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out)
     });
 }
 
+int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(dp && out && k >= 1, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(dp->A->device));
+        int64_t rlo, rhi; DBuf<int32_t> *ptr; int64_t K;
+        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
+        else { auto *D = static_cast<DpRun<double> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
+        CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+        const int64_t n = dp->A->n;
+        if (k == 1) { for (int64_t r = 0; r <= n; r++) out[r] = 1; return CP_OK; }
+        std::vector<int32_t> h((size_t)n + 1);
+        CP_HIP(hipMemcpyAsync(h.data(), ptr->p + (size_t)(k - 1) * (size_t)(n + 1), sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, dp->A->stream));
+        CP_HIP(hipStreamSynchronize(dp->A->stream));
+        for (int64_t r = 0; r <= n; r++) out[r] = (r < rlo || r > rhi) ? 0 : (int64_t)h[(size_t)r] + 1;
+        return CP_OK;
+    });
+}
+
+int32_t cp_dp_block_tables(cp_dp_t dp, int32_t *nplanes_out, int64_t *opt_out, int64_t *nets_out, int64_t *selfnets_out)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(dp && opt_out && nets_out, CP_EINVAL, "bad argument");
+        CP_HIP(hipSetDevice(dp->A->device));
+        int nb = 0;
+        if (dp->dtype == CP_I64) {
+            auto *D = static_cast<DpRun<int64_t> *>(dp->impl);
+            CP_REQUIRE(D->fast && D->work, CP_EUNSUPPORTED, "block tables exist on the O(n log^2 n) path only");
+            nb = dp_total_block_tables<int64_t>(dp->A, D->work, opt_out, nets_out, selfnets_out);
+        } else {
+            auto *D = static_cast<DpRun<double> *>(dp->impl);
+            CP_REQUIRE(D->fast && D->work, CP_EUNSUPPORTED, "block tables exist on the O(n log^2 n) path only");
+            nb = dp_total_block_tables<double>(dp->A, D->work, opt_out, nets_out, selfnets_out);
+        }
+        if (nplanes_out) *nplanes_out = nb;
+        return CP_OK;
+    });
+}
+
 int32_t cp_dp_destroy(cp_dp_t dp)
 {
     if (!dp) return CP_OK;

@@ -288,12 +288,24 @@ template <typename TC> __device__ __forceinline__ int32_t best_nl(const Best<TC,
 template <typename TC> __device__ __forceinline__ void best_set_nl(Best<TC, false> &, int32_t) {}
 template <typename TC> __device__ __forceinline__ void best_set_nl(Best<TC, true> &b, int32_t v) { b.nl = v; }
 
-template <typename TC, bool HYP>
-__device__ __forceinline__ Best<TC, HYP> better(const Best<TC, HYP> &a, const Best<TC, HYP> &b)   // a is earlier (larger p): wins ties
+// (member-wise selects on values: returning `cond ? b : a` through references makes the compiler select between the two
+//  ADDRESSES -- one of them often a global-memory record -- and keeps the local operand in private memory: 24-96 B of scratch
+//  per lane and 0.5 GB of HBM writes per launch of the streaming kernel in round 1's profile)
+template <typename TC>
+__device__ __forceinline__ Best<TC, false> best_sel(bool tb, const Best<TC, false> a, const Best<TC, false> b)
 {
-    if (a.p < 0) return b;
-    if (b.p < 0) return a;
-    return (b.v < a.v) ? b : a;
+    Best<TC, false> r; r.v = tb ? b.v : a.v; r.p = tb ? b.p : a.p; r.nn = tb ? b.nn : a.nn; return r;
+}
+template <typename TC>
+__device__ __forceinline__ Best<TC, true> best_sel(bool tb, const Best<TC, true> a, const Best<TC, true> b)
+{
+    Best<TC, true> r; r.v = tb ? b.v : a.v; r.p = tb ? b.p : a.p; r.nn = tb ? b.nn : a.nn; r.nl = tb ? b.nl : a.nl; r._pad = 0; return r;
+}
+template <typename TC, bool HYP>
+__device__ __forceinline__ Best<TC, HYP> better(const Best<TC, HYP> a, const Best<TC, HYP> b)   // a is earlier (larger p): wins ties
+{
+    const bool tb = a.p < 0 || (b.p >= 0 && b.v < a.v);
+    return best_sel<TC>(tb, a, b);
 }
 
 __device__ __forceinline__ int64_t shfl_up64(int64_t v, int o)
@@ -951,8 +963,9 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
                 }
                 if (sg < ns) {                          // the candidates from here on have this special on their right
                     const int32_t s1 = rdl(sv, sg), val = s1 & 0x7fffffff;
-                    if (s1 >= 0) cum += (val >= rcmp);
-                    else cum2 += (valid && val < rr);
+                    const bool first_list = s1 >= 0;        // (two unconditional adds: an if / else here becomes ONE add through a selected address, i.e. scratch)
+                    cum += (first_list && val >= rcmp);
+                    cum2 += (!first_list && valid && val < rr);
                 }
             }
             continue;
@@ -2302,6 +2315,37 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     bool ok = run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, false);
     CP_REQUIRE(ok, CP_EINTERNAL, "DP layer failed with exact counts");
 }
+
+// Table-level window on a finished layer (tests): the per-block winners the combine step merges.  For every bit plane b and
+// every row r (0-based) with bit b set, opt_out[b * (n+1) + r] = 1-based j of the RIGHTMOST arg-min of W[p] + f(p, r) over the
+// row's Fenwick block [r_b - 2^b, r_b) and nn_out / nl_out the net (self-net) count of that part; 0 where bit b is clear.
+// Valid for the rows the last dp_total_layer call computed.
+template <typename TC>
+int dp_total_block_tables(cp_csr_s *A, void *work_, int64_t *opt_out, int64_t *nn_out, int64_t *nl_out)
+{
+    auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
+    const int64_t n = A->n, n1 = n + 1;
+    CP_REQUIRE(Wk.n == n && Wk.opt.p, CP_EINVAL, "no layer has been computed by the O(n log^2 n) scheme on this handle");
+    const size_t plane = (size_t)Wk.nbits * (size_t)n1;
+    std::vector<int32_t> ho(plane), hn(plane), hl;
+    CP_HIP(hipMemcpyAsync(ho.data(), Wk.opt.p, plane * sizeof(int32_t), hipMemcpyDeviceToHost, A->stream));
+    CP_HIP(hipMemcpyAsync(hn.data(), Wk.nnopt.p, plane * sizeof(int32_t), hipMemcpyDeviceToHost, A->stream));
+    if (Wk.hyp && nl_out) { hl.resize(plane); CP_HIP(hipMemcpyAsync(hl.data(), Wk.nlopt.p, plane * sizeof(int32_t), hipMemcpyDeviceToHost, A->stream)); }
+    CP_HIP(hipStreamSynchronize(A->stream));
+    for (int b = 0; b < Wk.nbits; b++)
+        for (int64_t r = 0; r <= n; r++) {
+            const size_t o = (size_t)b * (size_t)n1 + (size_t)r;
+            opt_out[o] = 0; nn_out[o] = 0; if (nl_out) nl_out[o] = 0;
+            if (r == 0 || !((r >> b) & 1)) continue;
+            int t = 0; while (!((r >> t) & 1)) t++;
+            const size_t slot = (size_t)b * (size_t)n1 + (size_t)((n - (n >> t)) + (r >> (t + 1)));      // prow(r, n)
+            opt_out[o] = (int64_t)ho[slot] + 1; nn_out[o] = hn[slot];
+            if (nl_out && !hl.empty()) nl_out[o] = hl[slot];
+        }
+    return Wk.nbits;
+}
+template int dp_total_block_tables<int64_t>(cp_csr_s *, void *, int64_t *, int64_t *, int64_t *);
+template int dp_total_block_tables<double>(cp_csr_s *, void *, int64_t *, int64_t *, int64_t *);
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }

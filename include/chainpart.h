@@ -156,6 +156,14 @@ int32_t cp_dp_begin(cp_csr_t csr, int64_t K, int32_t combine, int32_t order, con
                     int64_t row_lo, int64_t row_hi, cp_dp_t *out);
 int32_t cp_dp_layer(cp_dp_t dp, int64_t k, const void *cst_prev_device, void *cst_cur_device);
 int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out);
+/* table-level windows for parity tests: the whole ptr[:, k] row of this rank's tile (0 outside the tile), and -- on the
+ * O(n log^2 n) path -- the per-block state the last cp_dp_layer(k >= 2) left behind: for bit plane b < nplanes and row
+ * j' = r + 1 with bit b of r set, opt_out[b*(n+1) + r] = the LARGEST j minimising cst_prev[j] + f(j, j', k) over the
+ * row's Fenwick block j - 1 in [r_b - 2^b, r_b) (r_b = r with the bits below b cleared), nets_out / selfnets_out the counts
+ * of that part; 0 where bit b is clear.  These are the candidates the layer's final combine merges into
+ * cst[j', k] / ptr[j', k] (DynamicSplitter.jl:36-43); arrays hold 31 * (n+1) entries (selfnets_out may be NULL). */
+int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out /* n+1 */);
+int32_t cp_dp_block_tables(cp_dp_t dp, int32_t *nplanes_out, int64_t *opt_out, int64_t *nets_out, int64_t *selfnets_out);
 int32_t cp_dp_destroy(cp_dp_t dp);
 
 /* ---- execution control / measurement ---- */

@@ -39,7 +39,7 @@ def first_last(A):
     return first, last
 
 
-def layer_total(A, Wprev, fcost, prev, nxt, first=None, last=None):
+def layer_total(A, Wprev, fcost, prev, nxt, first=None, last=None, blocks=False):
     """Return (cst[r], ptr[r]) for r in 0..n:  min over p<=r of Wprev[p] + fcost(p, r, nets(p,r)[, selfnets(p,r)]),
     ties -> largest p.  With first/last given the count is the pair (nets, selfnets) (hyperedge-cut costs):
     selfnets(p, r) = #rows with first >= p and last < r; a column c joining on the right of a part starting at B
@@ -106,4 +106,6 @@ def layer_total(A, Wprev, fcost, prev, nxt, first=None, last=None):
             if (r >> b) & 1 and val[r, b] < bv:
                 bv, bp = val[r, b], opt[r, b]
         cst[r], ptr[r] = bv, bp
+    if blocks:
+        return cst, ptr, opt.T.copy()          # opt[b, r]: the per-block winners the combine step merged
     return cst, ptr

@@ -61,3 +61,63 @@ def test_dc_scheme_hyperedge_cut(orc):
                 c2, p2 = dc_model.layer_total(A, W, fcost, prev, nxt, first, last)
                 assert [int(x) for x in p2 + 1] == ptr[:, k - 1].tolist(), (A, k, bs, bc)
                 assert [int(x) for x in c2] == [int(x) for x in cst[:, k - 1]]
+
+
+def _w_rows(rng, n, scale):
+    """previous-layer rows that are NOT the closed-form row: arbitrary, monotone, and tie-heavy ones"""
+    return [rng.integers(0, scale + 1, n + 1), np.sort(rng.integers(0, scale + 1, n + 1)),
+            np.sort(rng.integers(0, scale + 1, n + 1))[::-1].copy(), rng.integers(0, 3, n + 1),
+            np.zeros(n + 1, dtype=np.int64)]
+
+
+def test_brute_force_layer_is_the_oracles_layer(orc):
+    """tests/brute.py (counts from their definitions, the recurrence as written) reproduces the oracle's tables layer by
+    layer -- it may then stand in for the oracle where a previous-layer row is injected."""
+    import brute
+    rng = np.random.default_rng(7)
+    for A in [sprand(8, 16, 0.3, rng), sprand(10, 23, 0.2, rng), golden_matrices()["LPnetlib/lpi_itest6"], suitesparse_shaped(60, 3, 5)]:
+        for mdl in (cp.AffineConnectivityModel(0, 3, 1, 3), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3), cp.AffineWorkModel(1, 10, 1),
+                    cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[5, 1, 9, 2])):
+            K = 4
+            rc, ptr, cst = orc.dynamic_tables(A, K, 0, mdl.marshal(), None)
+            assert rc == 0
+            for k in range(2, K):
+                F = brute.cost_table(A, mdl, k)
+                c2, p2 = brute.layer(cst[:, k - 2], F)
+                assert np.array_equal(c2, cst[:, k - 1]) and np.array_equal(p2 + 1, ptr[:, k - 1])
+
+
+def test_dc_scheme_block_argmins_with_arbitrary_previous_rows():
+    """The closed form ptr[j'] = j' hides the per-block winners of the scheme for every true previous layer (the diagonal
+    candidate always ties the minimum).  W[p] + f(p, r) stays inverse-Monge for ANY row W, so inject rows that move the
+    arg-mins off the diagonal and compare BOTH the combined result and every per-block winner with brute force."""
+    import brute
+    rng = np.random.default_rng(99)
+    mats = [sprand(5, 7, 0.4, rng), sprand(8, 16, 0.3, rng), sprand(10, 23, 0.2, rng), sprand(6, 33, 0.3, rng), sprand(20, 40, 0.1, rng),
+            sprand(12, 31, 0.15, rng), suitesparse_shaped(50, 3, 5)]
+    nontrivial = 0
+    for A in mats:
+        n = A.n
+        prev, nxt = dc_model.link_arrays(A)
+        first, last = dc_model.first_last(A)
+        pos = A.colptr - 1
+        nb = max(1, int(n).bit_length())
+        for mdl in (cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(1, 2, 1, 3), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3)):
+            hyper = mdl.kind == cp.models.CP_MODEL_HYPEREDGE_CUT
+            F = brute.cost_table(A, mdl)
+            if hyper:
+                def fcost(p, r, c):
+                    nn, nl = int(c[0]), int(c[1])
+                    return mdl(r - p, int(pos[r] - pos[p]), nl, nn - nl)
+            else:
+                def fcost(p, r, nn):
+                    return mdl(r - p, int(pos[r] - pos[p]), nn)
+            for W in _w_rows(rng, n, int(F.max()) + 1):
+                Wl = [int(x) for x in W]
+                c2, p2, o2 = dc_model.layer_total(A, Wl, fcost, prev, nxt, *((first, last) if hyper else ()), blocks=True)
+                cb, pb = brute.layer(W, F)
+                assert [int(x) for x in c2] == cb.tolist() and p2.tolist() == pb.tolist()
+                ob = brute.block_argmins(W, F, nb)
+                assert np.array_equal(o2[:nb], ob), (A, mdl.kind)
+                nontrivial += int(np.sum(pb != np.arange(n + 1)))
+    assert nontrivial > 300          # the injected rows do move the winners off the diagonal
