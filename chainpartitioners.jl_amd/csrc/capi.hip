@@ -102,15 +102,14 @@ static bool model_known(const cp_model_t *m)
     return m->dtype == CP_I64 || m->dtype == CP_F64;
 }
 
-static bool all_integral(const cp_model_t *m) { return model_all_integral(m); }
 
 // is the O(n log^2 n) total-cost scheme exact for this model?  Needs W[p]+f(p,r) inverse-Monge:
 // modular terms (alpha, vertices, pins) are free; the net count is submodular, so beta_net >= 0;
 // hyperedge cost = d*b_cut + l*(b_self - b_cut) needs b_cut >= 0 and b_self <= b_cut.
 // Float64 models qualify only when every parameter is integer-valued (then all sums are exact).
-static bool fast_total_ok(const cp_model_t *m)
+static bool fast_total_ok(const cp_model_t *m, int64_t n, int64_t N, int64_t K)
 {
-    if (!all_integral(m)) return false;
+    if (!model_exact_on(m, n, N, K)) return false;      // (Float64: integer-valued parameters AND every reachable total below 2^53)
     auto P = [&](int i) { return m->dtype == CP_I64 ? (double)m->p_i64[i] : m->p_f64[i]; };
     if (m->kind == CP_MODEL_WORK) return true;
     if (m->kind == CP_MODEL_CONNECTIVITY) return P(CP_P_NET) >= 0;
@@ -145,7 +144,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     hipStream_t s = A->stream;
     int64_t n = A->n;
     bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
-    bool fast = combine == CP_COMBINE_SUM && fast_total_ok(mdl) && !g_opt_force_brute;
+    bool fast = combine == CP_COMBINE_SUM && fast_total_ok(mdl, A->n, A->N, K) && !g_opt_force_brute;
     if (!fast)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
@@ -265,7 +264,7 @@ static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, 
         D->mdl.alpha_k = D->alpha_k_host.data();
     }
     D->need_self = model->kind == CP_MODEL_HYPEREDGE_CUT;
-    D->fast = combine == CP_COMBINE_SUM && fast_total_ok(model) && !g_opt_force_brute;
+    D->fast = combine == CP_COMBINE_SUM && fast_total_ok(model, A->n, A->N, K) && !g_opt_force_brute;
     if (!D->fast)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
@@ -417,8 +416,7 @@ int32_t cp_csr_destroy(cp_csr_t A)
     if (!A) return CP_OK;
     (void)hipSetDevice(A->device);
     if (A->stream) (void)hipStreamSynchronize(A->stream);
-    if (A->own_stream && A->stream) (void)hipStreamDestroy(A->stream);
-    delete A;
+    delete A;                                        // (the destructor frees the DP scratch and the handle's own stream)
     return CP_OK;
 }
 
@@ -553,6 +551,10 @@ int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model
     (void)Pi;
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && ptr_out && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
+        CP_REQUIRE(model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT ||
+                       model->kind == CP_MODEL_COLBLOCK || model->kind == CP_MODEL_POWER_WORK,
+                   CP_EUNSUPPORTED, "model kind has no device DP path");
         CP_HIP(hipSetDevice(A->device));
         std::vector<int64_t> spl((size_t)K + 1);
         if (model->dtype == CP_I64) return run_dynamic<int64_t>(A, K, combine, CP_ORDER_SPLITTER, model, spl.data(), ptr_out, cst_i64);

@@ -48,8 +48,8 @@ struct DBuf {
     ~DBuf() { release(); }
     void alloc(size_t count) {
         release();
+        if (count) CP_HIP(hipMalloc((void **)&p, count * sizeof(T)));      // (throws with n == 0, p == nullptr: a failed buffer never claims a size)
         n = count;
-        if (count) CP_HIP(hipMalloc((void **)&p, count * sizeof(T)));
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }

@@ -215,15 +215,27 @@ void exclusive_scan_i32_i32(const int32_t *in, int32_t *out, int64_t n, DBuf<int
 }
 
 // ------------------------------------------------------------------ CSR upload / normalisation
-__global__ void k_norm_pos(const int64_t *__restrict__ colptr, int64_t *__restrict__ pos, int64_t n1)
+// The same pass validates what every later kernel indexes with: colptr[1] == 1, colptr non-decreasing, colptr[n+1] == nnz + 1,
+// 1 <= rowval <= m.  A violation sets *bad (the handle is refused with CP_EINVAL instead of a GPU fault in the link build).
+__global__ void k_norm_pos(const int64_t *__restrict__ colptr, int64_t *__restrict__ pos, int64_t n1, int64_t N, int32_t *__restrict__ bad)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n1) pos[i] = colptr[i] - 1;
+    if (i >= n1) return;
+    const int64_t c = colptr[i];
+    pos[i] = c - 1;
+    bool ok = c >= 1 && c <= N + 1;
+    if (i == 0) ok = ok && c == 1;
+    if (i == n1 - 1) ok = ok && c == N + 1;
+    if (i + 1 < n1) ok = ok && colptr[i + 1] >= c;
+    if (!ok) *bad = 1;
 }
-__global__ void k_norm_row(const int64_t *__restrict__ rowval, int32_t *__restrict__ row, int64_t N)
+__global__ void k_norm_row(const int64_t *__restrict__ rowval, int32_t *__restrict__ row, int64_t N, int64_t m, int32_t *__restrict__ bad)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) row[i] = (int32_t)(rowval[i] - 1);
+    if (i >= N) return;
+    const int64_t r = rowval[i];
+    if (r < 1 || r > m) { *bad = 1; row[i] = 0; return; }
+    row[i] = (int32_t)(r - 1);
 }
 
 void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool on_device)
@@ -232,6 +244,7 @@ void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool 
     A->pos.alloc((size_t)A->n + 1);
     A->row.alloc((size_t)(A->N > 0 ? A->N : 1));
     DBuf<int64_t> tmp_c, tmp_r;
+    DBuf<int32_t> bad(1);
     const int64_t *dc = colptr, *dr = rowval;
     if (!on_device) {
         tmp_c.alloc((size_t)A->n + 1);
@@ -240,11 +253,15 @@ void csr_upload(cp_csr_s *A, const int64_t *colptr, const int64_t *rowval, bool 
         if (A->N > 0) CP_HIP(hipMemcpyAsync(tmp_r.p, rowval, sizeof(int64_t) * (size_t)A->N, hipMemcpyHostToDevice, s));
         dc = tmp_c.p; dr = tmp_r.p;
     }
-    hipLaunchKernelGGL(k_norm_pos, dim3((unsigned)cdiv(A->n + 1, 256)), dim3(256), 0, s, dc, A->pos.p, A->n + 1);
+    CP_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_norm_pos, dim3((unsigned)cdiv(A->n + 1, 256)), dim3(256), 0, s, dc, A->pos.p, A->n + 1, A->N, bad.p);
     if (A->N > 0)
-        hipLaunchKernelGGL(k_norm_row, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, dr, A->row.p, A->N);
+        hipLaunchKernelGGL(k_norm_row, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, dr, A->row.p, A->N, A->m, bad.p);
     CP_HIP(hipGetLastError());
+    int32_t hb = 0;
+    CP_HIP(hipMemcpyAsync(&hb, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
+    CP_REQUIRE(!hb, CP_EINVAL, "malformed pattern: colptr must start at 1, be non-decreasing and end at nnz+1; rowval must lie in 1..m");
 }
 
 // ------------------------------------------------------------------ adjointpattern / download

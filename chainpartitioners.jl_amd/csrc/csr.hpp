@@ -33,7 +33,11 @@ struct cp_csr_s {
     void *dp_work[2] = {nullptr, nullptr};
     void (*dp_work_free_fn[2])(void *) = {nullptr, nullptr};
     void (*dp_work_reset_fn[2])(void *) = {nullptr, nullptr};
-    ~cp_csr_s() { for (int i = 0; i < 2; i++) if (dp_work[i] && dp_work_free_fn[i]) dp_work_free_fn[i](dp_work[i]); }
+    ~cp_csr_s()
+    {
+        for (int i = 0; i < 2; i++) if (dp_work[i] && dp_work_free_fn[i]) dp_work_free_fn[i](dp_work[i]);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);      // (also on the error paths of the create entry points)
+    }
 };
 
 namespace cpk {

@@ -1825,21 +1825,26 @@ struct LayerWork {
     DBuf<RoundCounts> rc;                               // per-round counters of the current layer (device)
     std::vector<RoundCounts> pred;                      // ... of the previous layer (host): sizes the next one
     bool pred_ok = false; int64_t pred_rlo = 0, pred_rhi = 0;
+    // (o_rec / loc are the size witnesses of their groups: they are released first and allocated LAST, so a hipMalloc failure in
+    //  the middle leaves the witness empty and the next call allocates the whole group again)
     void ensure_own(size_t NT) {                        // per-tile arrays of the own-tiled tasks
         if (o_rec.n >= NT && o_rec.n > 0) return;
         size_t c = NT > 0 ? NT : 1;
-        o_rec.alloc(c); o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c); o_hi.alloc(c); o_spec.alloc(c);
+        o_rec.release();
+        o_task.alloc(c); o_tileS.alloc(c); o_tilePS.alloc(c + 1); o_part.alloc(c); o_hi.alloc(c); o_spec.alloc(c);
         o_sub.alloc(c * (SMAX + 1)); o_spv.alloc(c * (SMAX + 1));
         if (hyp) { o_tileS2.alloc(c); o_tilePS2.alloc(c + 1); }
+        o_rec.alloc(c);
     }
     void ensure_flat(size_t T) {                        // per-step and per-tile arrays of the flattened tasks
         if (loc.n >= T && loc.n > 0) return;
         size_t c = T > 0 ? T : 1, nt = (c + LT - 1) / LT;
-        loc.alloc(c);
+        loc.release();
         if (hyp) loc2.alloc(c);
         tileS.alloc(nt); tilePS.alloc(nt + 1); tile_t0.alloc(nt); partL.alloc(nt); partR.alloc(nt); taskR.alloc(nt);
         open_list.alloc(nt); fix_list.alloc(nt); tile_rec.alloc(nt);
         if (hyp) { tileS2.alloc(nt); tilePS2.alloc(nt + 1); }
+        loc.alloc(c);
     }
 };
 
@@ -2287,7 +2292,8 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     while (((int64_t)1 << nbits) <= n) nbits++;
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
-        Wk.n = n; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false;
+        // (the shape is recorded only after every allocation succeeded: a hipMalloc failure leaves n == -1 and the next call starts over)
+        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false;
         Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
@@ -2307,6 +2313,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (hyp) Wk.o_tS0l.alloc(mo);
         Wk.rc.alloc((size_t)NBMAX + 2);
         Wk.fin.alloc(plane); Wk.last_s0.alloc(64);
+        Wk.n = n;
     }
     bool spec = Wk.pred_ok && Wk.pred_rlo == rlo && Wk.pred_rhi == rhi && !g_opt_nospec;
     if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;

@@ -8,6 +8,7 @@
 #pragma once
 #include "common.hpp"
 #include <cmath>
+#include <algorithm>
 
 namespace cpk {
 
@@ -115,6 +116,20 @@ inline bool model_all_integral(const cp_model_t *m)
     for (int i = 0; i < 5; i++) if (std::floor(m->p_f64[i]) != m->p_f64[i] || std::fabs(m->p_f64[i]) > 9e15) return false;
     if (m->alpha_k) for (int64_t i = 0; i < m->n_alpha_k; i++) { double v = ((const double *)m->alpha_k)[i]; if (std::floor(v) != v) return false; }
     return true;
+}
+
+// ... and bounded so: the exact-arithmetic paths (O(n log^2 n) DP, (min,+) chunk scan) reassociate sums and argue about ties, which
+// is only the reference's sequential Float64 arithmetic while every cost and every running total stays below 2^53.  Largest
+// reachable total of a K-part partition of an n-column, N-nonzero pattern: K*|alpha| + n*|b_vertex| + N*|b_pin| + N*max|b_net-like|.
+inline bool model_exact_on(const cp_model_t *m, int64_t n, int64_t N, int64_t K)
+{
+    if (!model_all_integral(m)) return false;
+    if (m->dtype == CP_I64) return true;
+    double amax = std::fabs(m->p_f64[CP_P_ALPHA]);
+    if (m->alpha_k) for (int64_t i = 0; i < m->n_alpha_k; i++) amax = std::max(amax, std::fabs(((const double *)m->alpha_k)[i]));
+    double bnet = std::max(std::fabs(m->p_f64[3]), std::fabs(m->p_f64[4]));
+    double bound = amax * (double)(K > 0 ? K : 1) + std::fabs(m->p_f64[CP_P_VERTEX]) * (double)n + std::fabs(m->p_f64[CP_P_PIN]) * (double)N + bnet * (double)N;
+    return bound < 9007199254740992.0;       // 2^53
 }
 
 // host: build a DevModel from the C-ABI struct, uploading alpha_k / tables

@@ -706,7 +706,7 @@ int32_t run_pack_dynamic(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t 
         // width-windowed costs whose sums are exact: parallel (min,+) scan (chunk_scan.hip); tables of block-component
         // models hold tabulated component values, which the host marshals as exact integers too
         bool scanned = false;
-        bool exact = std::is_same<TC, int64_t>::value || (model_all_integral(mdl) && mdl->kind != CP_MODEL_COLBLOCK);
+        bool exact = std::is_same<TC, int64_t>::value || (model_exact_on(mdl, n, A->N, n + 1) && mdl->kind != CP_MODEL_COLBLOCK);
         if (W.kind == CP_MODEL_VERTEX_COUNT && C->O.Ftab && C->O.Wc == wi && exact && !g_opt_force_brute)
             scanned = pack_dynamic_scan<TC>(s, n, wi, C->O.Ftab, cst.p, spl.p);
         if (!scanned)

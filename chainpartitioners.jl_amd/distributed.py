@@ -59,24 +59,29 @@ class TiledDP:
 
 def partition_stripe_tiled(hip, handle, n, K, method, *, device, group=None):
     """partition_stripe(A, K, Dynamic{Total,Bottleneck}{Splitter,Chunker}(f)) with the DP rows tiled over the ranks of
-    `group` (default: the world).  Every rank returns the same (K+1) split vector (1-based numpy int64)."""
+    `group` (default: the world).  Every rank returns the same (K+1) split vector (1-based numpy int64).
+
+    Ordering: the handle's kernels are enqueued on torch's CURRENT stream (cp_set_stream), the stream the collective is
+    ordered against, so layer k+1 cannot read `prev` before the gather of layer k has landed -- whatever stream context the
+    caller runs under.  The gather is in place: every rank's tile of `cur` is the send buffer (no clone, no device-wide sync)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     host_staged = dist.get_backend(group) == "gloo"      # CPU rehearsal of the same exchange (tests); RCCL works on HBM
+    stream = torch.cuda.current_stream(device)
+    hip.set_stream(handle, stream.cuda_stream)
     T = TiledDP(hip, handle, n, K, method, rank, world, device)
     try:
         T.step_layer(1)                                 # whole layer on every rank, no exchange
         T.swap()
         for k in range(2, K + 1):
-            T.step_layer(k)
-            torch.cuda.synchronize(device)
-            mine = T.my_slice(T.cur).clone()
+            T.step_layer(k)                             # (returns with the tile written: cp_dp_layer waits for its stream)
+            mine = T.my_slice(T.cur)
             if host_staged:
                 parts = [torch.empty(T.tile, dtype=mine.dtype) for _ in range(world)]
                 dist.all_gather(parts, mine.cpu(), group=group)
                 T.cur.copy_(torch.cat(parts).to(device))
             else:
-                dist.all_gather_into_tensor(T.cur, mine, group=group)  # RCCL: every rank's tile of cst[:, k]
+                dist.all_gather_into_tensor(T.cur, mine, group=group)  # RCCL, in place: every rank's tile of cst[:, k]
             T.swap()
         spl = np.zeros(K + 1, dtype=np.int64)
         spl[K] = n + 1
