@@ -1988,7 +1988,11 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     const int nbits = Wk.nbits;
     const double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
     const double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
-    const double step_bytes = 4.0 * (avg_deg + self_deg) + 24.0;
+    // bytes a step of the streaming kernels moves: the stepped column's link entries (4 B each; hyperedge costs: plus the rows starting
+    // in it), its 32-bit column pointer (4 B), the candidate's previous-layer cost (8 B), and the tile's record + partial
+    // (16 B + 16 B per 256 steps).  (Round 1 priced a step at 4 deg + 24 B -- 8-byte column pointers and a per-step descriptor share
+    // the kernels do not read -- which put the achieved rate above the box's copy rate.)
+    const double step_bytes = 4.0 * (avg_deg + self_deg) + 12.0 + 32.0 / (double)LT;
     const bool own_tiles = !(g_opt_dbg & 64);      // cp_set_option("dbg", 64): keep every long task in the flattened space
     const int NR = nbits + 1;
     CP_HIP(hipMemsetAsync(Wk.rc.p, 0, sizeof(RoundCounts) * (size_t)NR, s));

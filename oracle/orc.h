@@ -147,6 +147,14 @@ int32_t orc_dynamic_tables(int64_t m, int64_t n, int64_t N, const int64_t *pos, 
                            int64_t K, int32_t combine, const cp_model_t *mdl, const cp_rowpart_t *Pi,
                            int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
 
+/* the same for the ConstrainedCost splitter (DynamicSplitter.jl:206-258): the two WindowConstrainedMatrix tables written out
+ * densely ((n+1) x K column-major; a cell outside its window holds what reading it returns: 0 / typemax, :127-134) and the
+ * windows j'_lo[k], j'_hi[k] of column_constraints (:144-172).  Infeasible: CP_INFEASIBLE, windows still written. */
+int32_t orc_dynamic_tables_constrained(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                       int64_t K, int32_t combine, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                                       const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                                       int64_t *win_lo, int64_t *win_hi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,9 @@
     int32_t orc_api_dynamic_tables##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,         \
                                       int64_t, int32_t, const cp_model_t *, const cp_rowpart_t *,          \
                                       int64_t *, T *);                                                     \
+    int32_t orc_api_dynamic_tables_constrained##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t, int32_t, \
+                                                  const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, double,    \
+                                                  int64_t *, int64_t *, int64_t *, T *);                                            \
     int32_t orc_api_pack_dynamic##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,           \
                                     const cp_model_t *, const cp_rowpart_t *, const cp_model_t *, int64_t, \
                                     double, int64_t *, int64_t *);                                         \
@@ -108,6 +111,15 @@ int32_t orc_dynamic_tables(int64_t m, int64_t n, int64_t N, const int64_t *pos, 
 {
     return IS_I(mdl) ? orc_api_dynamic_tables_i64(m, n, N, pos, idx, K, combine, mdl, Pi, ptr_out, cst_i64)
                      : orc_api_dynamic_tables_f64(m, n, N, pos, idx, K, combine, mdl, Pi, ptr_out, cst_f64);
+}
+
+int32_t orc_dynamic_tables_constrained(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                                       int64_t K, int32_t combine, const cp_model_t *mdl, const cp_rowpart_t *Pi,
+                                       const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
+                                       int64_t *win_lo, int64_t *win_hi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+{
+    return IS_I(mdl) ? orc_api_dynamic_tables_constrained_i64(m, n, N, pos, idx, K, combine, mdl, Pi, weight, wmax_i64, wmax_f64, win_lo, win_hi, ptr_out, cst_i64)
+                     : orc_api_dynamic_tables_constrained_f64(m, n, N, pos, idx, K, combine, mdl, Pi, weight, wmax_i64, wmax_f64, win_lo, win_hi, ptr_out, cst_f64);
 }
 
 int32_t orc_pack_dynamic(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,

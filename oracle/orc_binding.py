@@ -142,6 +142,17 @@ class OracleBackend:
                                       _p(cst) if mm.struct.dtype == 1 else None)
         return rc, ptr.T, cst.T                               # [j', k] views
 
+    def dynamic_tables_constrained(self, A, K, combine, mm, rp, wm, wi, wf):
+        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of the ConstrainedCost splitter, tables densified"""
+        ptr = np.zeros((K, A.n + 1), dtype=np.int64)
+        cst = np.zeros((K, A.n + 1), dtype=np.int64 if mm.struct.dtype == 0 else np.float64)
+        lo = np.zeros(K, dtype=np.int64); hi = np.zeros(K, dtype=np.int64)
+        rc = lib().orc_dynamic_tables_constrained(*self._A(A), _i64(K), C.c_int32(combine), mm.ptr,
+                                                  C.byref(rp) if rp is not None else None, wm.ptr, _i64(wi), C.c_double(wf),
+                                                  _p(lo), _p(hi), _p(ptr),
+                                                  _p(cst) if mm.struct.dtype == 0 else None, _p(cst) if mm.struct.dtype == 1 else None)
+        return rc, lo, hi, ptr.T, cst.T
+
     # counting structures
     def count_build(self, kind, A, hint, b=0, H=0, bp=0):
         L = lib()
