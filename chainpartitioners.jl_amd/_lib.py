@@ -21,8 +21,8 @@ SYMBOLS = [
     "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise",
     "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
-    "cp_dynamic_tables", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
-    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables",
+    "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
+    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
     "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
 ]
@@ -209,6 +209,16 @@ class HipBackend:
                                         _p(cst) if mm.struct.dtype == M.CP_F64 else None)
         return rc, ptr.T, cst.T
 
+    def dynamic_tables_constrained(self, A, K, mm, wmax):
+        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of DynamicTotalSplitter(ConstrainedCost(f, VertexCount(), wmax))"""
+        ptr = np.zeros((K, A.n + 1), dtype=np.int64)
+        cst = np.zeros((K, A.n + 1), dtype=np.int64 if mm.struct.dtype == M.CP_I64 else np.float64)
+        lo = np.zeros(K, dtype=np.int64); hi = np.zeros(K, dtype=np.int64)
+        rc = self.lib.cp_dynamic_tables_constrained(self._h(A), _i64(K), mm.ptr, _i64(wmax), _p(lo), _p(hi), _p(ptr),
+                                                    _p(cst) if mm.struct.dtype == M.CP_I64 else None,
+                                                    _p(cst) if mm.struct.dtype == M.CP_F64 else None)
+        return rc, lo, hi, ptr.T, cst.T
+
     # ---- counting structures
     def count_build(self, kind, A, hint):
         h = C.c_void_p()
@@ -282,6 +292,24 @@ class HipBackend:
         k = nb.value
         return k, opt.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), nn.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), \
             (nl.reshape(-1)[:k * (n + 1)].reshape(k, n + 1) if hyper else None)
+
+    def windowed_layer(self, A, mm, W, wmax, lo=None, hi=None):
+        """one DP layer over injected previous costs W (numpy, n+1) with the width window wmax: (cst[r], ptr[r]) 0-based,
+        rows [lo, hi) 1-based like cp_dp_begin (default: all)"""
+        import torch
+        n = A.n
+        dev = torch.device("cuda", self.device)
+        dp = self.dp_begin(A, 3, 0, 0, mm, lo or 1, hi or n + 2)
+        try:
+            rc = self.lib.cp_dp_set_window(dp, _i64(wmax))
+            if rc != 0:
+                raise RuntimeError(f"cp_dp_set_window -> {rc}")
+            prev = torch.from_numpy(np.ascontiguousarray(W)).to(dev)
+            cur = torch.zeros(n + 1, dtype=prev.dtype, device=dev)
+            self.dp_layer(dp, 2, prev.data_ptr(), cur.data_ptr())
+            return cur.cpu().numpy(), self.dp_ptr_row(dp, 2, n) - 1
+        finally:
+            self.dp_destroy(dp)
 
     def dp_destroy(self, dp):
         self.lib.cp_dp_destroy(dp)

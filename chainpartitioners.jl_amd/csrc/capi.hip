@@ -228,6 +228,113 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     return CP_OK;
 }
 
+// ------------------------------------------------------------------ the K-part DP under a width constraint
+// partition_stripe(A, K, DynamicTotal{Splitter,Chunker}(ConstrainedCost(f, VertexCount(), w_max)))   DynamicSplitter.jl:206-314.
+// Layer k lives on the rows j' in [j'_lo[k], j'_hi[k]] (column_constraints :144-172; for the width weight: closed forms), its
+// candidates are j in [max(j'_lo[k-1], j' - w_max), min(j', j'_hi[k-1])] (:233-246), ties -> largest j.  The previous layer's
+// window enters through its cost row -- a value no real total reaches outside the window -- and the width through the windowed
+// geometry of dp_total_layer; the rows are restricted to the layer's window (the row-tile mechanism of the multi-GPU path).
+// The chunker loop order (:260-314) fills the same cells with the same recurrence (part_constraints :174-204 describes the
+// same windows column by column) and calls the cost without the part index.
+template <typename TC> struct BigCost;
+template <> struct BigCost<int64_t> { static __host__ __device__ int64_t v() { return (int64_t)1 << 61; } };
+template <> struct BigCost<double> { static __host__ __device__ double v() { return 1152921504606846976.0; } };      // 2^60
+
+// W[p] = cst[p] inside [lo, hi] (0-based rows), a huge value outside
+template <typename TC>
+__global__ void __launch_bounds__(256) k_mask_row(int64_t n1, int64_t lo, int64_t hi, const TC *__restrict__ cst, TC *__restrict__ W)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n1) W[p] = (p >= lo && p <= hi) ? cst[p] : BigCost<TC>::v();
+}
+
+static void width_windows(int64_t n, int64_t K, int64_t w, std::vector<int64_t> &lo, std::vector<int64_t> &hi)
+{
+    lo.assign((size_t)K + 1, 0); hi.assign((size_t)K + 1, 0);           // 1-based k, 1-based j'
+    int64_t jp = n + 1;
+    for (int64_t k = K; k >= 1; k--) { lo[(size_t)k] = jp; jp = std::max<int64_t>(1, jp > w ? jp - w : 1); }
+    int64_t j = 1;
+    for (int64_t k = 1; k <= K; k++) { hi[(size_t)k] = (w >= n + 1 - j) ? n + 1 : j + w; j = hi[(size_t)k]; }
+}
+
+template <typename TC>
+static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const cp_model_t *mdl, int64_t wmax,
+                                    int64_t *spl_out, int64_t *ptr_tab, TC *cst_tab, int64_t *win_lo, int64_t *win_hi)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n;
+    const size_t n1 = (size_t)n + 1;
+    std::vector<int64_t> lo, hi;
+    width_windows(n, K, wmax, lo, hi);
+    if (win_lo) for (int64_t k = 1; k <= K; k++) { win_lo[k - 1] = lo[(size_t)k]; win_hi[k - 1] = hi[(size_t)k]; }
+    if (ptr_tab) for (size_t i = 0; i < (size_t)K * n1; i++) { ptr_tab[i] = 0; cst_tab[i] = CostTraits<TC>::typemax(); }
+    if (hi[(size_t)K] < n + 1) {                                         // infeasible (:217-222): a degenerate partition, no exception
+        for (int64_t k = 0; k < K; k++) spl_out[k] = 1;
+        spl_out[K] = n + 1;
+        return CP_INFEASIBLE;
+    }
+    const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(n, 1));     // (wider than the matrix: every window is [0, r])
+    const bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
+    ensure_links(A);
+    if (need_self) ensure_self(A);
+    HostModel<TC> HM;
+    build_dev_model<TC>(mdl, HM, s);
+    DBuf<TC> cst(n1), Wm(n1);
+    DBuf<int32_t> ptr((size_t)K * n1);
+    DBuf<int32_t> cnt0((size_t)(n > 0 ? n : 1));
+    DBuf<int64_t> firsts(n1), scratch;
+    const bool has_nets = mdl->kind == CP_MODEL_CONNECTIVITY || mdl->kind == CP_MODEL_HYPEREDGE_CUT;
+    if (has_nets) {
+        if (n > 0) hipLaunchKernelGGL(k_col_count_prev_lt, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, A->pos.p, A->prev.p, 0, cnt0.p, n);
+        exclusive_scan_i32(cnt0.p, firsts.p, n, scratch, s);
+    }
+    auto alpha_of = [&](int64_t k) { return order == CP_ORDER_SPLITTER ? host_alpha<TC>(mdl, k) : model_param<TC>(mdl, CP_P_ALPHA); };
+    const unsigned g1 = (unsigned)cdiv((int64_t)n1, 256);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_layer1<TC>), dim3(g1), dim3(256), 0, s, n, A->pos.p, has_nets ? firsts.p : nullptr,
+                       need_self ? A->lpos.p : nullptr, HM.d, alpha_of(1), cst.p, ptr.p);
+    CP_HIP(hipGetLastError());
+    auto dump_layer = [&](int64_t k) {
+        if (!ptr_tab) return;
+        std::vector<TC> hc(n1);
+        std::vector<int32_t> hp(n1);
+        CP_HIP(hipMemcpyAsync(hc.data(), cst.p, sizeof(TC) * n1, hipMemcpyDeviceToHost, s));
+        CP_HIP(hipMemcpyAsync(hp.data(), ptr.p + (size_t)(k - 1) * n1, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+        CP_HIP(hipStreamSynchronize(s));
+        for (int64_t r = lo[(size_t)k] - 1; r <= hi[(size_t)k] - 1; r++) {
+            ptr_tab[(size_t)(k - 1) * n1 + (size_t)r] = (int64_t)hp[(size_t)r] + 1;
+            cst_tab[(size_t)(k - 1) * n1 + (size_t)r] = hc[(size_t)r];
+        }
+    };
+    dump_layer(1);
+    void *work = dp_total_work_get<TC>(A);
+    for (int64_t k = 2; k <= K; k++) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_row<TC>), dim3(g1), dim3(256), 0, s, (int64_t)n1, lo[(size_t)k - 1] - 1, hi[(size_t)k - 1] - 1, cst.p, Wm.p);
+        dp_total_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, work, lo[(size_t)k] - 1, hi[(size_t)k] - 1, w);
+        dump_layer(k);
+    }
+    // unravel_splits (DynamicSplitter.jl:89-99); every visited cell lies in its layer's window
+    std::vector<int64_t> spl((size_t)K + 1);
+    spl[(size_t)K] = n;
+    for (int64_t k = K; k >= 1; k--) {
+        int32_t v = 0;
+        CP_HIP(hipMemcpyAsync(&v, ptr.p + (size_t)(k - 1) * n1 + (size_t)spl[(size_t)k], sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CP_HIP(hipStreamSynchronize(s));
+        spl[(size_t)k - 1] = v;
+    }
+    for (int64_t k = 0; k <= K; k++) spl_out[k] = spl[(size_t)k] + 1;
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    return CP_OK;
+}
+
+// the scalable path takes: total cost, a model of the inverse-Monge class, the width weight, w_max >= 1
+static bool windowed_ok(cp_csr_s *A, int64_t K, int32_t combine, const cp_model_t *model, const cp_model_t *weight, int64_t wmax)
+{
+    return combine == CP_COMBINE_SUM && weight && weight->kind == CP_MODEL_VERTEX_COUNT && wmax >= 1 && !g_opt_force_brute &&
+           (model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT) &&
+           fast_total_ok(model, A->n, A->N, K);
+}
+
 // ------------------------------------------------------------------ row-tiled DP (one rank = one tile of rows per layer)
 // cp_dp_*: the same layers as run_dynamic, but a rank computes only rows [row_lo, row_hi) of every layer and the caller
 // completes the layer's cost vector with a collective (RCCL all_gather over xGMI) before the next layer.
@@ -236,6 +343,7 @@ template <typename TC>
 struct DpRun : DpBase {
     cp_csr_s *A = nullptr;
     int64_t K = 0, rlo = 0, rhi = 0;          // 0-based inclusive row window
+    int64_t wwin = 0;                          // > 0: layers k >= 2 take their candidates from the width window max(0, r - wwin) <= p <= r (cp_dp_set_window)
     int32_t combine = 0, order = 0;
     cp_model_t mdl{};
     std::vector<TC> alpha_k_host;
@@ -305,7 +413,8 @@ static int32_t dp_layer(DpRun<TC> *D, int64_t k, const TC *prev, TC *cur)
     CP_REQUIRE(prev && cur && k >= 2 && k <= D->K, CP_EINVAL, "bad layer");
     int64_t rlo = D->rlo < 0 ? 0 : D->rlo, rhi = D->rhi > n ? n : D->rhi;
     if (rhi >= rlo) {
-        if (D->fast) dp_total_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, D->work, rlo, rhi);
+        CP_REQUIRE(D->wwin == 0 || D->fast, CP_EUNSUPPORTED, "the width window needs the O(n log^2 n) path");
+        if (D->fast) dp_total_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, D->work, rlo, rhi, D->wwin);
         else dp_brute_layer<TC>(A, D->HM.d, D->alpha_of(k), D->combine, prev, cur, pk, rlo, rhi);
     }
     CP_HIP(hipStreamSynchronize(s));
@@ -534,6 +643,10 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
         if (constrained) {
             CP_REQUIRE(weight->kind == CP_MODEL_VERTEX_COUNT || (weight->kind == CP_MODEL_WORK && !weight->alpha_k), CP_EINVAL,
                        "weight must be VertexCount or an AffineWorkModel");
+            if (windowed_ok(A, K, combine, model, weight, wmax_i64)) {      // O(K n log^2 n): the windowed geometry of dp_total.hip
+                if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wmax_i64, spl_out, nullptr, nullptr, nullptr, nullptr);
+                return run_dynamic_windowed<double>(A, K, order, model, wmax_i64, spl_out, nullptr, nullptr, nullptr, nullptr);
+            }
             if (model->dtype == CP_I64) return run_dyn_constrained<int64_t>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
             return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         }
@@ -559,6 +672,20 @@ int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model
         std::vector<int64_t> spl((size_t)K + 1);
         if (model->dtype == CP_I64) return run_dynamic<int64_t>(A, K, combine, CP_ORDER_SPLITTER, model, spl.data(), ptr_out, cst_i64);
         return run_dynamic<double>(A, K, combine, CP_ORDER_SPLITTER, model, spl.data(), ptr_out, cst_f64);
+    });
+}
+
+int32_t cp_dynamic_tables_constrained(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t wmax, int64_t *win_lo, int64_t *win_hi,
+                                      int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+{
+    return guarded([&]() -> int32_t {
+        CP_REQUIRE(A && ptr_out && win_lo && win_hi && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        cp_model_t vc{}; vc.kind = CP_MODEL_VERTEX_COUNT; vc.dtype = CP_I64;
+        CP_REQUIRE(windowed_ok(A, K, CP_COMBINE_SUM, model, &vc, wmax), CP_EUNSUPPORTED, "outside the windowed O(n log^2 n) path");
+        CP_HIP(hipSetDevice(A->device));
+        std::vector<int64_t> spl((size_t)K + 1);
+        if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_i64, win_lo, win_hi);
+        return run_dynamic_windowed<double>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_f64, win_lo, win_hi);
     });
 }
 
@@ -815,6 +942,14 @@ int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out)
         *out = (int64_t)v + 1;
         return CP_OK;
     });
+}
+
+int32_t cp_dp_set_window(cp_dp_t dp, int64_t wmax)
+{
+    if (!dp || wmax < 0) return CP_EINVAL;
+    if (dp->dtype == CP_I64) static_cast<DpRun<int64_t> *>(dp->impl)->wwin = wmax;
+    else static_cast<DpRun<double> *>(dp->impl)->wwin = wmax;
+    return CP_OK;
 }
 
 int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out)

@@ -8,7 +8,8 @@ namespace cpk {
 // one layer of the total-cost DP by the O(n log^2 n) scheme (dp_total.hip)
 template <typename TC>
 void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work,
-                    int64_t rlo, int64_t rhi);      // computes rows r in [rlo, rhi] (0-based); the full range is [0, n]
+                    int64_t rlo, int64_t rhi,       // computes rows r in [rlo, rhi] (0-based); the full range is [0, n]
+                    int64_t wwin = 0);              // > 0: width window -- the candidates of row r are max(0, r - wwin) <= p <= r
 template <typename TC> int dp_total_block_tables(cp_csr_s *A, void *work, int64_t *opt_out, int64_t *nn_out, int64_t *nl_out);   // per-block winners of the last layer (tests)
 template <typename TC> void *dp_total_work_get(cp_csr_s *A);      // the handle's scratch for cost type TC (created on first use)
 template <typename TC> void *dp_total_work_new();

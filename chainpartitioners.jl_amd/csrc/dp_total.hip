@@ -59,8 +59,33 @@ __device__ __forceinline__ int64_t prow(int64_t r, int64_t n)
 }
 #define PR(x) prow((x), n1 - 1)
 
+// Width-windowed layers (the ConstrainedCost DP, DynamicSplitter.jl:206-258 with a VertexCount weight; executable spec:
+// tests/dc_model.py layer_windowed): candidates of row r are max(0, r - w) <= p <= r.  With s = floor(log2 w), S = 2^s, every row
+// has a task in EVERY plane b <= s:
+//   b < s, bit b of r set   : the standard Fenwick block [r_b - 2^b, r_b)
+//   b == s                  : the common block [rho - w + S - 1, rho), rho = r with the bits below s cleared
+//   b < s, bit b of r clear : the mirrored block [rho + 2^b - 1 - w, rho + 2^(b+1) - 1 - w), rho = r with the bits <= b cleared
+// (clamped at column 0).  The rows sharing a block are always the aligned block of 2^b rows holding r -- full rectangles again.
+struct Geo { int32_t win, s; int64_t w; };
+
+// candidates [cs, ce) of row r in plane b; false: the row has no task in this plane (or the block is empty)
+__host__ __device__ __forceinline__ bool geo_block(const Geo &G, int64_t r, int b, int64_t &cs, int64_t &ce)
+{
+    const int64_t lo = (r >> b) << b;
+    if (!G.win) { cs = lo - ((int64_t)1 << b); ce = lo; return (r >> b) & 1; }
+    if (b > G.s) return false;
+    if (b == G.s) { cs = lo - G.w + ((int64_t)1 << b) - 1; ce = lo; }
+    else if ((r >> b) & 1) { cs = lo - ((int64_t)1 << b); ce = lo; }
+    else { cs = lo + ((int64_t)1 << b) - 1 - G.w; ce = cs + ((int64_t)1 << b); }
+    if (cs < 0) cs = 0;
+    if (ce < 0) ce = 0;
+    return ce > cs;
+}
+
 struct RoundDesc {
     int32_t isA, tau, nbits, nextra;
+    Geo G;                      // G.win: nbits = s + 1 planes, every row takes part in each of them
+    int64_t aoff[32];           // windowed round A: anchors of the mirrored head tasks of plane b start at aoff[b] (index r >> (b+1))
     int64_t n, ntask;
     int64_t tbase[36];          // tau rounds: tasks of bit plane b occupy [tbase[b], tbase[b+1])
     int64_t tskip[36];          // ... and start at linear index tskip[b] of that plane (row-tiled runs skip rows left of the tile)
@@ -86,6 +111,16 @@ struct RoundCounts {
 
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
 {
+    if (R.G.win) {
+        // plane-major.  Round A: plane b <= s holds the rows that are multiples of 2^b (the heads of its rectangles);
+        // round tau: every plane b in (tau, s] holds all rows with ctz == tau
+        int bb = R.isA ? 0 : R.tau + 1;
+        while (t >= R.tbase[bb + 1]) bb++;
+        const int64_t l = t - R.tbase[bb] + R.tskip[bb];
+        r = R.isA ? ((l + 1) << bb) : (((l << 1) | 1) << R.tau);
+        b = bb;
+        return;
+    }
     if (R.isA) {
         if (t >= R.a_nmain + R.nextra) { r = R.n; b = R.last_b[t - R.a_nmain - R.nextra]; return; }
         r = t < R.a_nmain ? R.a_r0 + t : R.extra[t - R.a_nmain]; b = __ffsll((long long)r) - 1; return;
@@ -111,8 +146,10 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
-                                                     int32_t *__restrict__ cr)
+                                                     int32_t *__restrict__ cr, int allp)
 {
+    // allp (windowed layers): every row takes part in every plane tau < b < nbits (an empty block holds the threshold -1 or a
+    // stale value: its count is never read)
     int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = u < nrows;
     u += u0;
@@ -129,7 +166,7 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
         cnt[b] = 0;
         thr[b] = ge ? INT32_MAX : INT32_MIN;
         if (b <= tau || b >= nbits) continue;                  // wave-uniform
-        bool on = (r >> b) & 1;
+        bool on = live && (allp || ((r >> b) & 1));
         if (!__ballot(on)) continue;                           // wave-uniform
         used |= 1u << b;
         int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
@@ -154,14 +191,14 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++)
-        if (b > tau && b < nbits && ((r >> b) & 1)) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
+        if (b > tau && b < nbits && (allp || ((r >> b) & 1))) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
 }
 
 // Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
 template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, int chunks_per_row, int ch_cols,
                                                     const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
-                                                    const int32_t *__restrict__ opt, int32_t *__restrict__ cr)
+                                                    const int32_t *__restrict__ opt, int32_t *__restrict__ cr, int allp)
 {
     int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
@@ -181,7 +218,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
         cnt[b] = 0;
         thr[b] = ge ? INT32_MAX : INT32_MIN;
         if (b <= tau || b >= nbits) continue;
-        bool on = (r >> b) & 1;
+        bool on = allp || ((r >> b) & 1);
         int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
         if (on) thr[b] = v;
     }
@@ -192,14 +229,14 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
                 v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
-            if (b <= tau || b >= nbits || !((r >> b) & 1)) continue;      // wave-uniform: only the planes of this row's set bits
+            if (b <= tau || b >= nbits || !(allp || ((r >> b) & 1))) continue;      // wave-uniform: only the planes of this row's set bits
             int32_t t = thr[b];
             cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
         }
     }
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {
-        bool on = b > tau && b < nbits && ((r >> b) & 1);          // wave-uniform
+        bool on = b > tau && b < nbits && (allp || ((r >> b) & 1));          // wave-uniform
         if (on) {
             int32_t c = cnt[b];
             for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
@@ -365,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
                                                       unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
                                                       int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0,
-                                                      int32_t *__restrict__ dbg_ntriv)
+                                                      int32_t *__restrict__ dbg_ntriv, const int32_t *__restrict__ anch, const int32_t *__restrict__ anch2)
 {
     int lane = threadIdx.x & 63;
     bool live;
@@ -382,14 +419,36 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         live = l < R.tbase[b + 1] - R.tbase[b];
         if (live) {
             l += R.tskip[b];
+            if (R.G.win) r = ((l << 1) | 1) << R.tau;            // windowed layers: every row with ctz == tau, in every plane
+            else {
             int sh = b - R.tau - 1;
             int64_t base = l >> sh, v = l & (((int64_t)1 << sh) - 1);
             r = (base << (b + 1)) | ((int64_t)1 << b) | (((v << 1) | 1) << R.tau);
+            }
             // (rows of a tau round have ctz == tau: their plane slot needs no bit search)
             if (fin && fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))]) live = false;      // finished by a gap pass of an earlier round
         }
     }
-    if (live) {
+    if (live && R.G.win) {
+        // windowed geometry: the block of (r, b); round A: the head row of a rectangle scans the whole block below the virtual
+        // candidate B = block end, anchor = nets(block end, r) (0 for the standard and common blocks, which end at r; cached per
+        // partition for the mirrored ones); round tau: bounds from the tree neighbours inside the row block of 2^b rows
+        const int64_t n1 = R.n + 1;
+        int64_t cs, ce;
+        if (!geo_block(R.G, r, b, cs, ce)) live = false;
+        else if (R.isA) {
+            B = ce; a = cs;
+            if (ce != r) { S0 = anch[R.aoff[b] + (r >> (b + 1))]; if (HYP) S0l = anch2[R.aoff[b] + (r >> (b + 1))]; }
+        } else {
+            const int64_t rL = r - ((int64_t)1 << R.tau), rR = r + ((int64_t)1 << R.tau), rect_hi = ((r >> b) + 1) << b;
+            B = opt[(int64_t)b * n1 + PR(rL)];
+            S0 = (int64_t)nnopt[(int64_t)b * n1 + PR(rL)] + cr[(int64_t)b * n1 + PR(r)];
+            if (HYP) S0l = (int64_t)nlopt[(int64_t)b * n1 + PR(rL)] + crl[(int64_t)b * n1 + PR(r)];
+            a = (rR < rect_hi && rR <= R.n) ? (int64_t)opt[(int64_t)b * n1 + PR(rR)] : cs;
+            if (a > B) a = B;
+        }
+    }
+    if (live && !R.G.win) {
         int64_t n1 = R.n + 1;
         if (R.isA) {
             // B = r_b is virtual (not a candidate).  Rows r == r_b: nothing lies right of B, anchor 0; the last row n in a
@@ -407,6 +466,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             a = (rR - rb) < ((int64_t)1 << b) ? (int64_t)opt[(int64_t)b * n1 + PR(rR <= R.n ? rR : R.n)] : rb - ((int64_t)1 << b);
             if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
         }
+    }
+    if (live) {
         int64_t L = 1 + (B - a);
         if (dbg_ntriv && L > 1 && !R.isA) atomicAdd(dbg_ntriv, 1);
         is_short = L <= SHORT_T && (pos32[B] - pos32[a]) <= SHORT_E && (!HYP || (fpos32[B] - fpos32[a]) <= SHORT_E);
@@ -1630,6 +1691,101 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t
     ptr[r] = (int32_t)bp;
 }
 
+// windowed layers: the candidates of row r from the right: the diagonal, the standard planes by ascending bit, the common plane,
+// the mirrored planes by descending bit -- strict < while moving left keeps the largest p on ties
+template <typename TC>
+__global__ void __launch_bounds__(256) k_combine_win(Geo G, int64_t n, int64_t rlo, int64_t rhi, const int64_t *__restrict__ pos,
+                                                     const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
+                                                     const int32_t *__restrict__ nlopt,
+                                                     const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                     TC *__restrict__ cst, int32_t *__restrict__ ptr)
+{
+    int64_t r = rlo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rhi) return;
+    const int64_t n1 = n + 1;
+    TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
+    int64_t bp = r;
+    if (r >= 1) {
+        const int64_t slot = PR(r);
+        for (int i = 0; i <= 2 * G.s; i++) {
+            const int b = i <= G.s ? i : 2 * G.s - i;                       // 0 .. s, then s-1 .. 0
+            if (b < G.s && (((r >> b) & 1) != (i <= G.s))) continue;      // first pass: set bits (standard); second pass: clear bits (mirrored)
+            if (b == G.s && i != G.s) continue;
+            int64_t cs, ce;
+            if (!geo_block(G, r, b, cs, ce)) continue;
+            const int64_t p = opt[(int64_t)b * n1 + slot];
+            const int64_t nn = nnopt[(int64_t)b * n1 + slot];
+            const int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + slot] : 0;
+            const TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, nl));
+            if (v < bv) { bv = v; bp = p; }
+        }
+    }
+    cst[r] = bv;
+    ptr[r] = (int32_t)bp;
+}
+
+// ---- anchors of the mirrored head tasks (windowed layers), once per (pattern, w)
+// hist[e]++ for e = min(next[q], col[q] + w, n): then  nets(max(0, r - w), r) = pos[r] - #{q : e(q) < r}   (an entry is counted by
+// the window ending before r iff it lies in a column < r, is the LAST occurrence of its row before r, and its column is >= r - w)
+__global__ void __launch_bounds__(256) k_win_hist(int64_t N, int64_t n, int64_t w, const int32_t *__restrict__ col, const int32_t *__restrict__ next,
+                                                  int32_t *__restrict__ hist)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    int64_t e = (int64_t)col[q] + w, nx = next[q];
+    if (nx < e) e = nx;
+    if (e > n) e = n;
+    atomicAdd(&hist[e], 1);
+}
+// the same for whole rows (self nets): rows with first >= r - w and last < r  =  #{last < r} - #{max(last, first + w) < r}
+__global__ void __launch_bounds__(256) k_win_hist_rows(int64_t m, int64_t n, int64_t w, const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
+                                                       int32_t *__restrict__ hist)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int64_t f = rfirst[i];
+    if (f < 0) return;                                      // empty row
+    int64_t e = f + w, l = rlast[i];
+    if (l > e) e = l;
+    if (e > n) e = n;
+    atomicAdd(&hist[e], 1);
+}
+// one wave per mirrored head (plane b < s, rho = idx << (b+1)): entries of the block's columns passing the test
+//   tot[aoff[b] + idx] = #{q in the columns of the block : next[q] >= rho}   (GE)   /   #{rows starting in the block with last < rho}
+template <bool GE>
+__global__ void __launch_bounds__(256) k_win_block_totals(RoundDesc R, int64_t nitems, const int32_t *__restrict__ cpos, const int32_t *__restrict__ arr,
+                                                          int32_t *__restrict__ tot)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < nitems; it += (int64_t)gridDim.x * 4) {
+        int b = 0;
+        while (it >= R.aoff[b + 1]) b++;
+        const int64_t idx = it - R.aoff[b], rho = idx << (b + 1);
+        int32_t c = 0;
+        int64_t cs, ce;
+        if (idx >= 1 && rho <= R.n && geo_block(R.G, rho, b, cs, ce)) {
+            const int32_t thr = (int32_t)rho;
+            for (int32_t q = cpos[cs] + lane, q1 = cpos[ce]; q < q1; q += 64) { const int32_t v = arr[q]; c += GE ? (v >= thr) : (v < thr); }
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) tot[it] = c;
+    }
+}
+// anchor of (b, rho) = count of the whole window [max(0, rho - w), rho) minus the totals of the blocks b' <= b left of the block's end
+__global__ void __launch_bounds__(256) k_win_anchors(RoundDesc R, int64_t nitems, const int64_t *__restrict__ base, const int64_t *__restrict__ E,
+                                                     const int32_t *__restrict__ tot, int32_t *__restrict__ anch)
+{
+    int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= nitems) return;
+    int b = 0;
+    while (it >= R.aoff[b + 1]) b++;
+    const int64_t idx = it - R.aoff[b], rho = idx << (b + 1);
+    if (idx < 1 || rho > R.n) { anch[it] = 0; return; }
+    int64_t v = base[rho] - E[rho];
+    for (int bb = 0; bb <= b; bb++) v -= tot[R.aoff[bb] + (rho >> (bb + 1))];
+    anch[it] = (int32_t)v;
+}
+
 // ------------------------------------------------------------------ round A from cached counts
 // Round A (row r against its lowest block [r - 2^b, r), b = ctz(r)) is the one round whose candidate ranges do not depend on
 // the layer: nets(p, r) for all its (row, candidate) pairs -- sum_r 2^ctz(r) = n log2(n) / 2 values -- is computed ONCE per
@@ -1822,9 +1978,14 @@ struct LayerWork {
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
+    // windowed layers: geometry of the current call; anchors of the mirrored head tasks, cached per (pattern, w)
+    Geo G{0, 0, 0};
+    bool win_built = false; int64_t win_w = -1, win_nitems = 0, win_aoff[33];
+    DBuf<int32_t> w_anch, w_anch2, w_tot, w_hist;
+    DBuf<int64_t> w_E;
     DBuf<RoundCounts> rc;                               // per-round counters of the current layer (device)
     std::vector<RoundCounts> pred;                      // ... of the previous layer (host): sizes the next one
-    bool pred_ok = false; int64_t pred_rlo = 0, pred_rhi = 0;
+    bool pred_ok = false; int64_t pred_rlo = 0, pred_rhi = 0; double pred_scale = 1.0; int pred_win = 0; int64_t pred_w = 0;
     // (o_rec / loc are the size witnesses of their groups: they are released first and allocated LAST, so a hipMalloc failure in
     //  the middle leaves the witness empty and the next call allocates the whole group again)
     void ensure_own(size_t NT) {                        // per-tile arrays of the own-tiled tasks
@@ -1864,10 +2025,39 @@ static int64_t count_rows(int b, int tau, int64_t x)
 // Rows computed by a run restricted to the row tile [rlo, rhi]: every row r with
 //     r - 2^ctz(r) <= rhi  and  r + 2^ctz(r) >= rlo
 // -- the tile plus the O(log n) tree ancestors its rows take their candidate bounds from (closed under ancestors).
-static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, int64_t rlo, int64_t rhi)
+static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, int64_t rlo, int64_t rhi, const Geo &G = Geo{0, 0, 0},
+                       const int64_t *aoff = nullptr)
 {
     memset(&R, 0, sizeof(R));
-    R.isA = isA; R.tau = tau; R.nbits = nbits; R.n = n;
+    R.isA = isA; R.tau = tau; R.nbits = nbits; R.n = n; R.G = G;
+    if (G.win) {
+        // every row takes part in every plane b <= s.  Round A: plane b holds the heads of its rectangles, the multiples of 2^b
+        // (index l <-> row (l + 1) << b); round tau: every plane b in (tau, s] holds the rows with ctz == tau (index l <-> row
+        // (2 l + 1) << tau).  A row tile [rlo, rhi] needs the rows within 2^tau of it in round tau (their tree neighbours are then
+        // computed by the earlier rounds) and the heads within 2^(b+1) of it in plane b.
+        if (aoff) for (int b = 0; b < 32; b++) R.aoff[b] = aoff[b];
+        int64_t acc = 0;
+        for (int b = 0; b < 36; b++) {
+            R.tbase[b] = acc;
+            if (b > G.s || (!isA && b <= tau)) continue;
+            if (isA) {
+                int64_t lo = rlo - ((int64_t)2 << b), hi = rhi + ((int64_t)1 << b);
+                if (lo < ((int64_t)1 << b)) lo = (int64_t)1 << b;
+                if (hi > n) hi = n;
+                int64_t l0 = ((lo + ((int64_t)1 << b) - 1) >> b) - 1, l1 = (hi >> b) - 1;      // first / last head index
+                R.tskip[b] = l0;
+                acc += l1 >= l0 ? l1 - l0 + 1 : 0;
+            } else {
+                int64_t rmin = rlo - ((int64_t)1 << tau), rmax = rhi + ((int64_t)1 << tau);
+                if (rmax > n) rmax = n;
+                int64_t u0 = rmin <= 0 ? 0 : (((rmin - 1) >> tau) + 1) >> 1, u1 = ((rmax >> tau) + 1) >> 1;
+                R.tskip[b] = u0;
+                acc += u1 > u0 ? u1 - u0 : 0;
+            }
+        }
+        R.ntask = acc;
+        return;
+    }
     if (isA) {
         int64_t r0 = rlo > 1 ? rlo : 1, r1 = rhi < n ? rhi : n;
         R.a_r0 = r0; R.a_nmain = r1 >= r0 ? r1 - r0 + 1 : 0;
@@ -1911,6 +2101,7 @@ static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, in
 static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n, int64_t rlo, int64_t rhi, const int64_t *cpos,
                          const int32_t *link, int ge, const int32_t *opt, int32_t *cr)
 {
+    const int allp = R.G.win;
     int tau = R.tau;
     int64_t rmin = rlo - ((int64_t)1 << tau), rmax = rhi + ((int64_t)1 << tau);
     if (rmax > n) rmax = n;
@@ -1921,15 +2112,15 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     int64_t nrows = u1 - u0;
     if (nrows <= 0) return;
     if (tau <= g_opt_rpass_small_tau) {
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr);
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr, allp);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr, allp);
     } else {
         int ch_cols = (int)g_opt_rpass_ch;          // columns per wave (cp_set_option("rpass_ch"))
         int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
         if (cpr == 1) ch_cols = 1 << tau;
         int64_t waves = nrows * cpr;
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr);
+        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr, allp);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr, allp);
     }
 }
 
@@ -1971,6 +2162,39 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
     Wk.ra_built = true;
 }
 
+// anchors of the mirrored head tasks of the windowed layers (k_win_*): once per (pattern, w)
+template <typename TC>
+static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n, w = Wk.G.w;
+    const int sb = Wk.G.s;
+    int64_t acc = 0;
+    for (int b = 0; b < 33; b++) { Wk.win_aoff[b] = acc; if (b < sb) acc += (n >> (b + 1)) + 1; }      // heads of plane b: rho = idx << (b+1), idx <= n >> (b+1)
+    Wk.win_nitems = acc;
+    const size_t ni = (size_t)(acc > 0 ? acc : 1);
+    Wk.w_anch.ensure(ni); Wk.w_tot.ensure(ni); Wk.w_hist.ensure((size_t)n + 2); Wk.w_E.ensure((size_t)n + 2);
+    if (Wk.hyp) Wk.w_anch2.ensure(ni);
+    Wk.win_built = false;
+    if (acc > 0) {
+        RoundDesc R;
+        make_round(R, true, 0, sb + 1, n, 0, n, Wk.G, Wk.win_aoff);
+        const unsigned wg = (unsigned)std::min<int64_t>(cdiv(acc, 4), 65536);
+        for (int pass = 0; pass < (Wk.hyp ? 2 : 1); pass++) {
+            CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
+            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, A->N, n, w, A->col.p, A->next.p, Wk.w_hist.p); }
+            else if (A->m > 0) hipLaunchKernelGGL(k_win_hist_rows, dim3((unsigned)cdiv(A->m, 256)), dim3(256), 0, s, A->m, n, w, A->rfirst.p, A->rlast.p, Wk.w_hist.p);
+            exclusive_scan_i32(Wk.w_hist.p, Wk.w_E.p, n + 1, Wk.scratch, s);
+            if (pass == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_win_block_totals<true>), dim3(wg), dim3(256), 0, s, R, acc, A->pos32.p, A->next.p, Wk.w_tot.p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_win_block_totals<false>), dim3(wg), dim3(256), 0, s, R, acc, A->fpos32.p, A->flast.p, Wk.w_tot.p);
+            hipLaunchKernelGGL(k_win_anchors, dim3((unsigned)cdiv(acc, 256)), dim3(256), 0, s, R, acc, pass == 0 ? A->pos.p : A->lpos.p, Wk.w_E.p, Wk.w_tot.p,
+                               pass == 0 ? Wk.w_anch.p : Wk.w_anch2.p);
+        }
+        CP_HIP(hipGetLastError());
+    }
+    Wk.win_built = true; Wk.win_w = w;
+}
+
 constexpr int64_t LB_MAX = 1 << 20;      // largest scan (elements) done in a single launch
 
 // Runs the rounds of one layer.  `spec`: the per-round counts of the PREVIOUS layer (Wk.pred) size the grids, the buffers and
@@ -1985,7 +2209,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     hipStream_t s = A->stream;
     const int64_t n = A->n;
     const bool hyp = Wk.hyp;
-    const int nbits = Wk.nbits;
+    const Geo G = Wk.G;
+    const int nbits = G.win ? G.s + 1 : Wk.nbits;          // windowed layers: planes 0 .. s
     const double avg_deg = n > 0 ? (double)A->N / (double)n : 0.0;
     const double self_deg = (hyp && n > 0) ? (double)A->nrows_nonempty / (double)n : 0.0;
     // bytes a step of the streaming kernels moves: the stepped column's link entries (4 B each; hyperedge costs: plus the rows starting
@@ -2007,9 +2232,9 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
 
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
-        if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi);
-        else make_round(R, false, nbits - rd, nbits, n, rlo, rhi);
-        if (rd == 0 && g_opt_ra_cache && rlo <= 1 && rhi >= n && n >= 1) {
+        if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi, G, Wk.win_aoff);
+        else make_round(R, false, nbits - rd, nbits, n, rlo, rhi, G, Wk.win_aoff);
+        if (rd == 0 && g_opt_ra_cache && rlo <= 1 && rhi >= n && n >= 1 && !G.win) {
             // a full layer: round A of the rows' lowest blocks from the cached counts; what is left of round A below is the
             // last row in its upper planes
             if (!Wk.ra_built) { ProfScope ps(PROF_LINKS, s, 0.0); ra_build<TC>(A, Wk); }
@@ -2054,7 +2279,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
-                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr
+                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr, Wk.w_anch.p, Wk.w_anch2.p
             dim3 sgrid((unsigned)cdiv(R.ntask, 1024));
             if (!R.isA) {                                // one grid row per bit plane above tau
                 int64_t mx = 1;
@@ -2068,6 +2293,11 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundCounts P;                                   // the counts this round is sized with
         if (spec) {
             P = Wk.pred[(size_t)rd];
+            if (Wk.pred_scale != 1.0) {              // (windowed layers: the previous layer's tile had another number of rows)
+                auto sc = [&](int64_t v) { return (int64_t)((double)v * Wk.pred_scale) + (v > 0 ? 1 : 0); };
+                P.nlong = (int32_t)sc(P.nlong); P.nown = (int32_t)sc(P.nown); P.T = sc(P.T); P.NT = sc(P.NT);
+                P.own_steps = (unsigned long long)sc((int64_t)P.own_steps);
+            }
             if ((g_opt_dbg & 1024) && (rd & 1)) { P.nown = 0; P.NT = 0; P.nlong = 0; P.T = 0; }      // test: a prediction that skips stages with work
             // buffers from the prediction (grown only here; k_round_finish checks the true totals against them)
             Wk.ensure_own((size_t)grow(P.NT));
@@ -2257,7 +2487,10 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
         int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
-        if (c1 >= c0)
+        if (c1 >= c0 && G.win)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(c1 - c0 + 1, 256)), dim3(256), 0, s, G, n, c0, c1, A->pos.p,
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
+        else if (c1 >= c0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(c1 - c0 + 1, 256)), dim3(256), 0, s, n, c0, c1, nbits, A->pos.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
@@ -2280,14 +2513,14 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             if (pt.idx < g_prof_pending.size())
                 g_prof_pending[pt.idx].bytes = (pt.kind == 0 ? (double)g.own_steps : (double)g.T) * step_bytes;
         }
-        Wk.pred = got; Wk.pred_ok = true; Wk.pred_rlo = rlo; Wk.pred_rhi = rhi;
+        Wk.pred = got; Wk.pred_ok = true; Wk.pred_rlo = rlo; Wk.pred_rhi = rhi; Wk.pred_win = G.win; Wk.pred_w = G.w;
     }
     return ok;
 }
 
 template <typename TC>
 void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, void *work_,
-                    int64_t rlo, int64_t rhi)
+                    int64_t rlo, int64_t rhi, int64_t wwin)
 {
     auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
     int64_t n = A->n;
@@ -2319,7 +2552,22 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         Wk.fin.alloc(plane); Wk.last_s0.alloc(64);
         Wk.n = n;
     }
-    bool spec = Wk.pred_ok && Wk.pred_rlo == rlo && Wk.pred_rhi == rhi && !g_opt_nospec;
+    // geometry of this call: wwin > 0: candidates of row r are max(0, r - wwin) <= p <= r
+    Geo G{0, 0, 0};
+    if (wwin > 0) { G.win = 1; G.w = wwin; G.s = 0; while (((int64_t)2 << G.s) <= wwin) G.s++; if (G.s > nbits - 1) G.s = nbits - 1; }
+    // (w >= 2^(nbits-1) > n/2: planes 0 .. nbits-1 with S = 2^(nbits-1) <= w still tile every window -- the common block just
+    //  reaches further left than column 0 and is clamped)
+    Wk.G = G;
+    if (G.win && (!Wk.win_built || Wk.win_w != wwin)) win_build<TC>(A, Wk);
+    bool spec = Wk.pred_ok && !g_opt_nospec && Wk.pred_win == G.win && Wk.pred_w == G.w;
+    Wk.pred_scale = 1.0;
+    if (spec && (Wk.pred_rlo != rlo || Wk.pred_rhi != rhi)) {
+        // another row tile than the layer the counts come from: the unconstrained driver keeps its tile, the constrained one moves
+        // a window over the rows -- take the prediction per row of the tile
+        const double a = (double)(Wk.pred_rhi - Wk.pred_rlo + 1), b = (double)(rhi - rlo + 1);
+        if (!G.win || a < 1 || b < 1) spec = false;
+        else Wk.pred_scale = b / a;
+    }
     if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;
     // the prediction missed (a stage that had been empty, or a buffer too small): the same layer again with exact counts
     g_spec_redo++;
@@ -2360,7 +2608,7 @@ template int dp_total_block_tables<double>(cp_csr_s *, void *, int64_t *, int64_
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
-template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; }
+template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; W->win_built = false; }
 template <typename TC> void *dp_total_work_get(cp_csr_s *A)
 {
     const int i = sizeof(TC) == sizeof(double) && ((TC)0.5 != (TC)0) ? 1 : 0;
@@ -2371,8 +2619,8 @@ template void *dp_total_work_get<int64_t>(cp_csr_s *);
 template void *dp_total_work_get<double>(cp_csr_s *);
 template <typename TC> void dp_total_work_free(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
 
-template void dp_total_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, void *, int64_t, int64_t);
-template void dp_total_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, void *, int64_t, int64_t);
+template void dp_total_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, void *, int64_t, int64_t, int64_t);
+template void dp_total_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, void *, int64_t, int64_t, int64_t);
 template void *dp_total_work_new<int64_t>();
 template void *dp_total_work_new<double>();
 template void dp_total_work_free<int64_t>(void *);

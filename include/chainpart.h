@@ -142,6 +142,15 @@ int32_t cp_pack_equi(int64_t n, int64_t w, int64_t *spl_out /* cld(n,w)+1 */, in
 int32_t cp_dynamic_tables(cp_csr_t csr, int64_t K, int32_t combine, const cp_model_t *model,
                           const cp_rowpart_t *Pi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
 
+/* the same window on the ConstrainedCost splitter with the width weight (DynamicSplitter.jl:206-258,
+ * DynamicTotalSplitter(ConstrainedCost(f, VertexCount(), w_max))): win_lo / win_hi receive j'_lo[k] / j'_hi[k] of
+ * column_constraints (:144-172), the tables are written densely ((n+1) x K column-major; a cell outside its window holds what
+ * the reference's WindowConstrainedMatrix returns for it, 0 / typemax, :127-134).  Infeasible windows: CP_INFEASIBLE.
+ * Only the models the O(K n log^2 n) path takes (else CP_EUNSUPPORTED). */
+int32_t cp_dynamic_tables_constrained(cp_csr_t csr, int64_t K, const cp_model_t *model, int64_t wmax,
+                                      int64_t *win_lo /* K */, int64_t *win_hi /* K */,
+                                      int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
+
 /* ---- row-tiled DP: one process per GPU, the layer's cost vector is completed by the caller's collective ----
  * The rows j' of every DP layer (DynamicSplitter.jl:33-46: all cst[j',k] of a layer depend only on layer k-1) are
  * tiled contiguously over the ranks.  Rank g calls cp_dp_begin with its tile [row_lo, row_hi) (1-based, half-open,
@@ -163,6 +172,10 @@ int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out);
  * of that part; 0 where bit b is clear.  These are the candidates the layer's final combine merges into
  * cst[j', k] / ptr[j', k] (DynamicSplitter.jl:36-43); arrays hold 31 * (n+1) entries (selfnets_out may be NULL). */
 int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out /* n+1 */);
+/* layers k >= 2 computed after this call take their candidates from the width window j' - w_max <= j <= j' (the candidate
+ * range of the ConstrainedCost splitter with a VertexCount weight, DynamicSplitter.jl:233-246); 0 restores the full range.
+ * The layer windows j'_lo / j'_hi are the caller's business (the row tile, and a huge cost outside the previous window). */
+int32_t cp_dp_set_window(cp_dp_t dp, int64_t wmax);
 int32_t cp_dp_block_tables(cp_dp_t dp, int32_t *nplanes_out, int64_t *opt_out, int64_t *nets_out, int64_t *selfnets_out);
 int32_t cp_dp_destroy(cp_dp_t dp);
 

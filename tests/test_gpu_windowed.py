@@ -1,0 +1,131 @@
+"""GPU parity of the width-constrained DP, DynamicTotal{Splitter,Chunker}(ConstrainedCost(f, VertexCount(), w_max))
+(DynamicSplitter.jl:206-314) on the O(K n log^2 n) windowed path of csrc/dp_total.hip.  Unlike the unconstrained DP its
+answer is NOT closed-form (the split vectors are non-degenerate), so `spl` itself discriminates:
+  * every in-window cst / ptr cell and the windows j'_lo / j'_hi against the oracle's tables (cp_dynamic_tables_constrained);
+  * split vectors against the oracle, both loop orders, all driver options;
+  * the windowed layer kernel driven directly with injected previous rows against brute force (tests/brute.py);
+  * against the one-wave literal kernel (force_brute) at a size the oracle does not reach.
+"""
+import numpy as np
+import pytest
+import torch
+
+import brute
+from util import cp, sprand, golden_matrices, suitesparse_shaped, banded
+
+pytestmark = pytest.mark.gpu
+
+MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineWorkModel(0, 10, 1),
+          cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3),
+          cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0), cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[5, 1, 9, 2, 7, 3, 8, 4])]
+
+
+def mats():
+    rng = np.random.default_rng(0xDEADBEEF)
+    out = [sprand(m, n, p, rng) for (m, n, p) in [(3, 2, 0.5), (5, 7, 0.4), (8, 16, 0.3), (10, 23, 0.2), (6, 33, 0.3), (20, 40, 0.1),
+                                                  (9, 64, 0.2), (9, 65, 0.2), (9, 63, 0.2), (40, 100, 0.05), (4, 8, 0.0)]]
+    out += list(golden_matrices().values())
+    out += [suitesparse_shaped(1000, 6, 3), banded(777, 4, 0.5, 9)]
+    return out
+
+
+def widths(n, K):
+    ws = {max(1, -(-n // K)), max(1, -(-3 * n // (2 * K))), max(1, n // 2), max(1, n - 1), n + 3, 1, 2, 3, 5, 8}
+    return sorted(ws)
+
+
+@pytest.mark.parametrize("mi", range(len(MODELS)))
+def test_constrained_tables_bit_exact(hip, orc, mi):
+    mdl = MODELS[mi]
+    nondeg = 0
+    for A in mats():
+        for K in (1, 2, 5, 8):
+            for w in widths(A.n, K):
+                mm = mdl.marshal()
+                wm = cp.VertexCount().marshal()
+                rc2, lo2, hi2, p2, c2 = orc.dynamic_tables_constrained(A, K, 0, mm, None, wm, w, float(w))
+                rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w)
+                assert rc1 == rc2, (A, K, w, hip.last_error())
+                assert np.array_equal(lo1, lo2) and np.array_equal(hi1, hi2), (A, K, w)
+                if rc2 == 0:
+                    assert np.array_equal(p1, p2), (A, K, w, mi)
+                    assert np.array_equal(c1, c2), (A, K, w, mi)
+                for meth in (cp.DynamicTotalSplitter, cp.DynamicTotalChunker):
+                    f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
+                    got = cp.partition_stripe(A, K, meth(f), backend=hip)
+                    want = cp.partition_stripe(A, K, meth(f), backend=orc)
+                    assert got == want, (A, K, w, mi, meth.__name__)
+                nondeg += int(len(set(want.spl.tolist())) > 2)
+    assert nondeg > 100
+
+
+OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
+           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"dbg": 1024}, {"dbg": 2048}]
+DEFAULTS = {"nospec": 0, "gap_tau": 5, "gap_min": 64, "dbg": 0, "rpass_small_tau": 3, "rpass_ch": 512, "short_t": 4, "short_e": 64, "own_min": 64}
+
+
+@pytest.mark.parametrize("oi", range(len(OPTIONS)))
+def test_constrained_every_layer_option(hip, orc, oi):
+    mats_ = [suitesparse_shaped(3000, 8, 1), banded(2500, 6, 0.5, 3), suitesparse_shaped(1025, 5, 7)]
+    try:
+        for k, v in OPTIONS[oi].items():
+            assert hip.set_option(k, v) == 0
+        for A in mats_:
+            for mdl in (MODELS[0], MODELS[1], MODELS[4]):
+                for (K, w) in [(4, -(-3 * A.n // 8)), (7, A.n // 4), (16, A.n // 8), (3, 700)]:
+                    mm = mdl.marshal()
+                    rc2, lo2, hi2, p2, c2 = orc.dynamic_tables_constrained(A, K, 0, mm, None, cp.VertexCount().marshal(), w, float(w))
+                    rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w)
+                    assert rc1 == rc2 == 0, hip.last_error()
+                    assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (OPTIONS[oi], A, K, w)
+    finally:
+        for k, v in DEFAULTS.items():
+            hip.set_option(k, v)
+
+
+def test_windowed_layer_with_injected_rows(hip):
+    """the layer kernel itself: min over max(0, r - w) <= p <= r of W[p] + f(p, r) for arbitrary rows W (rows that are not a
+    DP layer move the winners around inside the window), against brute force"""
+    rng = np.random.default_rng(17)
+    moved = 0
+    for A in [sprand(9, 65, 0.2, rng), sprand(40, 100, 0.05, rng), suitesparse_shaped(1500, 6, 5), banded(1200, 5, 0.5, 2)]:
+        n = A.n
+        NT, ST = brute.net_table(A), brute.selfnet_table(A)
+        for mdl in (MODELS[1], MODELS[4]):
+            F = brute.cost_table(A, mdl, 2, NT, ST)
+            scale = int(abs(F).max()) + 1
+            for w in sorted({1, 2, 3, 7, 33, n // 5, n // 2, n}):
+                rows = [rng.integers(0, scale + 1, n + 1), np.sort(rng.integers(0, scale + 1, n + 1)), rng.integers(0, 3, n + 1),
+                        np.where(rng.random(n + 1) < 0.02, 0, scale * 8).astype(np.int64)]
+                for W in rows:
+                    cst, ptr = hip.windowed_layer(A, mdl.marshal(), W.astype(np.int64), w)
+                    lo = np.maximum(0, np.arange(n + 1) - w)
+                    cb, pb = brute.layer(W, F, lo=lo)
+                    assert np.array_equal(ptr, pb), (A, w)
+                    assert np.array_equal(cst, cb), (A, w)
+                    moved += int(np.sum(pb != np.arange(n + 1)))
+    assert moved > 10000
+
+
+def test_windowed_path_equals_literal_kernel_beyond_the_oracle(hip):
+    """n = 2e5, K = 8, w = ceil(1.5 n / K): the O(K n log^2 n) path against the one-wave literal kernel (force_brute)"""
+    A = suitesparse_shaped(200_000, 8, 42)
+    K = 8
+    w = -(-3 * A.n // (2 * K))
+    for mdl in (MODELS[0], MODELS[1]):
+        f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
+        fast = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=hip)
+        assert len(set(fast.spl.tolist())) == K + 1            # a non-degenerate answer
+        assert np.all(np.diff(fast.spl) <= w)
+        # the literal kernel is Theta(sum of window^2) on one wave: run it on a prefix-sized problem only
+    B = suitesparse_shaped(6000, 8, 43)
+    for mdl in (MODELS[0], MODELS[1], MODELS[4]):
+        for (K, w) in [(8, 1125), (5, 1500), (16, 500)]:
+            f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
+            fast = cp.partition_stripe(B, K, cp.DynamicTotalSplitter(f), backend=hip)
+            hip.set_option("force_brute", 1)
+            try:
+                lit = cp.partition_stripe(B, K, cp.DynamicTotalSplitter(f), backend=hip)
+            finally:
+                hip.set_option("force_brute", 0)
+            assert fast == lit
