@@ -2255,6 +2255,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             R.a_nmain = 0; R.ntask = R.nextra + R.nlast;
         }
         if (R.ntask <= 0) continue;
+        CP_REQUIRE(R.ntask <= Wk.max_tasks, CP_EINTERNAL, "a DP round has more tasks than the task buffers hold");
         RoundCounts *rc = Wk.rc.p + rd;
         const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
         if (!R.isA) {
@@ -2535,8 +2536,20 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
         if (hyp) { Wk.nlopt.alloc(plane); Wk.crl.alloc(plane); }
+        // The winners are zeroed once: a speculatively sized layer may skip a stage that turns out to have work (the layer is then
+        // redone), and until the redo later rounds read plane cells nobody wrote.  Whatever they hold must be a valid column
+        // index -- a stale winner of an earlier layer is, fresh device memory is not (a k_lpass_own wave once streamed from
+        // column 13868 of a 3000-column matrix).
+        CP_HIP(hipMemsetAsync(Wk.opt.p, 0, Wk.opt.bytes(), A->stream));
+        CP_HIP(hipMemsetAsync(Wk.nnopt.p, 0, Wk.nnopt.bytes(), A->stream));
+        CP_HIP(hipMemsetAsync(Wk.cr.p, 0, Wk.cr.bytes(), A->stream));
+        if (hyp) { CP_HIP(hipMemsetAsync(Wk.nlopt.p, 0, Wk.nlopt.bytes(), A->stream)); CP_HIP(hipMemsetAsync(Wk.crl.p, 0, Wk.crl.bytes(), A->stream)); }
         int64_t mx = n;
         for (int tau = 0; tau < nbits; tau++) { RoundDesc R; make_round(R, false, tau, nbits, n, 0, n); if (R.ntask > mx) mx = R.ntask; }
+        // windowed layers give every row of a round a task in EVERY plane above tau (up to nbits - 1 - tau of them), and round A
+        // one per head: sum_b (n >> b) < 2 n
+        for (int tau = 0; tau < nbits; tau++) mx = std::max<int64_t>(mx, ((n >> (tau + 1)) + 1) * (int64_t)(nbits - 1 - tau));
+        mx = std::max<int64_t>(mx, 2 * n + nbits);
         Wk.max_tasks = mx > 0 ? mx : 1;
         size_t mt = (size_t)Wk.max_tasks;
         Wk.tdesc.alloc(mt); Wk.len.alloc(mt); Wk.tb.alloc(mt); Wk.offs.alloc(mt + 1);

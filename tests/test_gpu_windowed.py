@@ -72,12 +72,12 @@ def test_constrained_every_layer_option(hip, orc, oi):
             assert hip.set_option(k, v) == 0
         for A in mats_:
             for mdl in (MODELS[0], MODELS[1], MODELS[4]):
-                for (K, w) in [(4, -(-3 * A.n // 8)), (7, A.n // 4), (16, A.n // 8), (3, 700)]:
+                for (K, w) in [(4, -(-3 * A.n // 8)), (7, A.n // 4), (16, A.n // 8), (3, A.n // 3 + 97), (3, 700)]:
                     mm = mdl.marshal()
                     rc2, lo2, hi2, p2, c2 = orc.dynamic_tables_constrained(A, K, 0, mm, None, cp.VertexCount().marshal(), w, float(w))
                     rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w)
-                    assert rc1 == rc2 == 0, hip.last_error()
-                    assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (OPTIONS[oi], A, K, w)
+                    assert rc1 == rc2 and rc1 in (0, 2), hip.last_error()          # 2: infeasible windows (K w_max < n)
+                    assert rc1 == 2 or (np.array_equal(p1, p2) and np.array_equal(c1, c2)), (OPTIONS[oi], A, K, w)
     finally:
         for k, v in DEFAULTS.items():
             hip.set_option(k, v)
@@ -115,7 +115,7 @@ def test_windowed_path_equals_literal_kernel_beyond_the_oracle(hip):
     for mdl in (MODELS[0], MODELS[1]):
         f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
         fast = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=hip)
-        assert len(set(fast.spl.tolist())) == K + 1            # a non-degenerate answer
+        assert len(set(fast.spl.tolist())) >= -(-A.n // w) + 1   # a non-degenerate answer: at least ceil(n / w) non-empty parts
         assert np.all(np.diff(fast.spl) <= w)
         # the literal kernel is Theta(sum of window^2) on one wave: run it on a prefix-sized problem only
     B = suitesparse_shaped(6000, 8, 43)
