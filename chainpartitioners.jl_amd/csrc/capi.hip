@@ -117,6 +117,19 @@ static bool fast_total_ok(const cp_model_t *m, int64_t n, int64_t N, int64_t K)
     return false;
 }
 
+// is the valley search of dp_bottleneck.hip exact for this model?  Needs a cost that grows with its part: every beta >= 0
+// (hyperedge cut: cost = d*b_cut + l*(b_self - b_cut) with d, l growing, so b_cut >= 0 and b_self >= b_cut).  alpha, alpha[k]
+// and the element type are free (no sums are reassociated: a max of two values).
+static bool fast_bottleneck_ok(const cp_model_t *m)
+{
+    auto P = [&](int i) { return m->dtype == CP_I64 ? (double)m->p_i64[i] : m->p_f64[i]; };
+    if (!(P(CP_P_VERTEX) >= 0 && P(CP_P_PIN) >= 0)) return false;
+    if (m->kind == CP_MODEL_WORK) return true;
+    if (m->kind == CP_MODEL_CONNECTIVITY) return P(CP_P_NET) >= 0;
+    if (m->kind == CP_MODEL_HYPEREDGE_CUT) return P(CP_P_CUT_NET) >= 0 && P(CP_P_SELF_NET) >= P(CP_P_CUT_NET);
+    return false;
+}
+
 template <typename TC> static TC host_alpha(const cp_model_t *m, int64_t k)
 {
     if (m->alpha_k && k >= 1 && k <= m->n_alpha_k) return ((const TC *)m->alpha_k)[k - 1];
@@ -145,7 +158,8 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     int64_t n = A->n;
     bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
     bool fast = combine == CP_COMBINE_SUM && fast_total_ok(mdl, A->n, A->N, K) && !g_opt_force_brute;
-    if (!fast)
+    const bool fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(mdl) && !g_opt_force_brute;
+    if (!fast && !fast_bn)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
     ensure_links(A);
@@ -195,6 +209,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
         int32_t *pk = ptr.p + (size_t)(k - 1) * n1;
         bool last = (k == K);
         if (fast) dp_total_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, work, last ? n : 0, n);   // layer K: row n+1 only (:34)
+        else if (fast_bn) dp_bottleneck_layer<TC>(A, HM.d, alpha_of(k), prevc, curc, pk, last ? n : 0, n);
         else dp_brute_layer<TC>(A, HM.d, alpha_of(k), combine, prevc, curc, pk, last ? n : 0, n);   // layer K: row n+1 only (:34)
         dump_layer(k, curc, last);
         if (fp_ok && !last) {
@@ -348,7 +363,7 @@ struct DpRun : DpBase {
     cp_model_t mdl{};
     std::vector<TC> alpha_k_host;
     HostModel<TC> HM;
-    bool fast = false, need_self = false;
+    bool fast = false, fast_bn = false, need_self = false;
     void *work = nullptr;
     DBuf<int32_t> ptr;                         // K x (n+1); only the tile rows of layers >= 2 are meaningful
     ~DpRun() {}                                  // (the layer scratch belongs to the handle)
@@ -373,7 +388,8 @@ static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, 
     }
     D->need_self = model->kind == CP_MODEL_HYPEREDGE_CUT;
     D->fast = combine == CP_COMBINE_SUM && fast_total_ok(model, A->n, A->N, K) && !g_opt_force_brute;
-    if (!D->fast)
+    D->fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(model) && !g_opt_force_brute;
+    if (!D->fast && !D->fast_bn)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
     ensure_links(A);
@@ -415,6 +431,7 @@ static int32_t dp_layer(DpRun<TC> *D, int64_t k, const TC *prev, TC *cur)
     if (rhi >= rlo) {
         CP_REQUIRE(D->wwin == 0 || D->fast, CP_EUNSUPPORTED, "the width window needs the O(n log^2 n) path");
         if (D->fast) dp_total_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, D->work, rlo, rhi, D->wwin);
+        else if (D->fast_bn) dp_bottleneck_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, rlo, rhi);
         else dp_brute_layer<TC>(A, D->HM.d, D->alpha_of(k), D->combine, prev, cur, pk, rlo, rhi);
     }
     CP_HIP(hipStreamSynchronize(s));
@@ -589,6 +606,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "fixed_point")) { g_opt_fixed_point = value; return CP_OK; }
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
+    if (!strcmp(name, "bn_chunk")) { g_opt_bn_chunk = value < 1 ? 1 : value; return CP_OK; }
     set_error("unknown option");
     return CP_EINVAL;
 }

@@ -456,6 +456,7 @@ void drop_cache(cp_csr_s *A)
 {
     A->have_links = false; A->have_self = false;
     for (int i = 0; i < 2; i++) if (A->dp_work[i] && A->dp_work_reset_fn[i]) A->dp_work_reset_fn[i](A->dp_work[i]);
+    if (A->bn_work && A->bn_work_reset_fn) A->bn_work_reset_fn(A->bn_work);
     // (the arrays themselves stay allocated: the next build refills them -- a multi-GB hipFree + hipMalloc pair per call buys nothing)
 }
 

@@ -33,9 +33,14 @@ struct cp_csr_s {
     void *dp_work[2] = {nullptr, nullptr};
     void (*dp_work_free_fn[2])(void *) = {nullptr, nullptr};
     void (*dp_work_reset_fn[2])(void *) = {nullptr, nullptr};
+    // state of the bottleneck DP layers (wavelet counters for the chunk starts, per-layer scratch): dp_bottleneck.hip
+    void *bn_work = nullptr;
+    void (*bn_work_free_fn)(void *) = nullptr;
+    void (*bn_work_reset_fn)(void *) = nullptr;
     ~cp_csr_s()
     {
         for (int i = 0; i < 2; i++) if (dp_work[i] && dp_work_free_fn[i]) dp_work_free_fn[i](dp_work[i]);
+        if (bn_work && bn_work_free_fn) bn_work_free_fn(bn_work);
         if (own_stream && stream) (void)hipStreamDestroy(stream);      // (also on the error paths of the create entry points)
     }
 };

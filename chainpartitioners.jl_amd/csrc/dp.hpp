@@ -21,6 +21,12 @@ template <typename TC>
 void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combine, const TC *W, TC *cst_out,
                     int32_t *ptr_out, int64_t r_lo, int64_t r_hi);
 
+// one layer of the bottleneck (g = max) DP for costs that grow with their part, by the valley search (dp_bottleneck.hip)
+template <typename TC>
+void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
+                         int64_t r_lo, int64_t r_hi);
+extern int64_t g_opt_bn_chunk;                 // rows per two-pointer walk (one lane each)
+
 // seq.hip
 template <typename TC>
 int32_t run_dyn_constrained(cp_csr_s *A, int64_t K, int32_t g, int32_t order, const cp_model_t *mdl, const cp_rowpart_t *Pi,

@@ -1,0 +1,212 @@
+// dp_bottleneck.hip -- one layer of the bottleneck (g = max) K-part DP in O(n) column steps, exact to the reference's literal
+// O(n^2) sweep including ties (largest j wins):
+//
+//     cst[j',k] = min_{1<=j<=j'} max(cst[j,k-1], f(j,j',k))        /root/reference/src/DynamicSplitter.jl:7,33-46
+//
+// For a cost that grows with its part (every beta >= 0; bound_stripe asserts the same, ConnectivityCosts.jl:25-27) the previous
+// layer W[p] = cst[p+1,k-1] is non-decreasing in p and f(p, r) is non-increasing in p, so h(p) = max(W[p], f(p, r)) is a valley:
+// with the CROSSING c(r) = min{p <= r : W[p] >= f(p, r)} (r + 1 if there is none),
+//     h(p) = f(p, r) below c (non-increasing),   h(p) = W[p] from c on (non-decreasing),
+// the minimum is min(f(c-1, r), W[c]) and the LARGEST minimiser -- the reference scans j upwards with <= -- is
+//     W[c] <= f(c-1, r):  the right end of W's run of equal values through c, capped at r;      otherwise  c - 1.
+// (SURVEY.md section 7 sketches this search; executable check against the recurrence: tests/test_oracle_bottleneck.py.)
+// The crossing is non-decreasing in r, so a chunk of consecutive rows is one two-pointer walk: moving r adds a column on the
+// right of the part [c, r), moving c removes one on its left, both are one pass over the column's link entries
+//     nets(c, r+1) = nets(c, r) + #{q in col r : prev[q] < c},      nets(c+1, r) = nets(c, r) - #{q in col c : next[q] >= r}
+// (self nets of the hyperedge-cut cost: rows bucketed by last / first column).  2 N link entries per layer in total.  The walk
+// of a chunk starts at its first row's crossing, found by a binary search over p with random-access counts from the wavelet
+// counter (the reference's NetCount / SelfNetCount query, SparseColorArrays.jl:121-125, 225-229).
+// Floating point: every term of the affine models is monotone in its count and IEEE addition is monotone, so the valley
+// holds for non-integral Float64 parameters as well; max() is exact.
+#include "csr.hpp"
+#include "model.hpp"
+#include "dp.hpp"
+#include "wavelet.hpp"
+
+namespace cpk {
+
+template <typename TC>
+struct BnCtx {
+    DevModel<TC> M; TC alpha;
+    int64_t n; int32_t hyp;
+    const int64_t *pos, *lpos;
+    const int32_t *pos32, *prev, *next, *fpos32, *flast, *lpos32, *lfirst;
+    WaveletDev net, self;
+    const TC *W;
+};
+
+template <typename TC>
+__device__ __forceinline__ TC bn_cost(const BnCtx<TC> &C, int64_t p, int64_t r, int64_t nn, int64_t nl)
+{
+    return dm_apply(C.M, C.alpha, r - p, (int64_t)(C.pos32[r] - C.pos32[p]), nn, nl);
+}
+
+// runend[p] = last index of the run of equal values of W through p (W is non-decreasing: runs are contiguous)
+//   pass 1: per block of 1024 rows, local answer or "continues beyond the block" (-1); pass 2: blocks resolved right to left by
+//   one thread (n / 1024 steps); pass 3: fill
+template <typename TC>
+__global__ void __launch_bounds__(1024) k_bn_run1(int64_t n1, const TC *__restrict__ W, int32_t *__restrict__ runend, int32_t *__restrict__ blk_first_end)
+{
+    __shared__ int32_t s_end[1024];
+    const int64_t base = (int64_t)blockIdx.x * 1024, p = base + threadIdx.x;
+    // e[p] = p if the run ends at p (p is the last row or W[p+1] differs), else "unknown"
+    int32_t e = INT32_MAX;
+    if (p < n1) e = (p == n1 - 1 || W[p + 1] != W[p]) ? (int32_t)p : INT32_MAX;
+    s_end[threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                    // suffix minimum inside the block
+        int32_t v = threadIdx.x + o < 1024 ? s_end[threadIdx.x + o] : INT32_MAX;
+        __syncthreads();
+        if (v < s_end[threadIdx.x]) s_end[threadIdx.x] = v;
+        __syncthreads();
+    }
+    if (p < n1) runend[p] = s_end[threadIdx.x];            // INT32_MAX: the run continues into the next block
+    if (threadIdx.x == 0) blk_first_end[blockIdx.x] = s_end[0];
+}
+__global__ void k_bn_run2(int64_t nblk, int32_t *__restrict__ blk_first_end)
+{
+    // blk_first_end[b] = end of the run that starts (or continues) at the first row of block b; resolved from the right
+    for (int64_t b = nblk - 2; b >= 0; b--) if (blk_first_end[b] == INT32_MAX) blk_first_end[b] = blk_first_end[b + 1];
+}
+__global__ void __launch_bounds__(1024) k_bn_run3(int64_t n1, int64_t nblk, int32_t *__restrict__ runend, const int32_t *__restrict__ blk_first_end)
+{
+    const int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (p < n1 && runend[p] == INT32_MAX) runend[p] = blockIdx.x + 1 < nblk ? blk_first_end[blockIdx.x + 1] : (int32_t)(n1 - 1);
+}
+
+// counts of the part [p, r) by random access
+template <typename TC>
+__device__ __forceinline__ void bn_counts(const BnCtx<TC> &C, int64_t p, int64_t r, int64_t &nn, int64_t &nl)
+{
+    nn = 0; nl = 0;
+    if (p >= r) return;
+    if (C.M.kind != CP_MODEL_WORK) nn = (C.pos[r] - C.pos[p]) - wt_count_le(C.net, C.n - p, C.pos[r]);
+    if (C.hyp) nl = wt_count_le(C.self, C.n - p, C.lpos[r]);
+}
+
+// first row of every chunk: its crossing by binary search (the predicate W[p] >= f(p, r) is monotone in p)
+template <typename TC>
+__global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk,
+                                                   int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunk) return;
+    const int64_t r = rlo + t * CH;
+    int64_t lo = 0, hi = r + 1;                             // the answer lies in [0, r + 1]
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;                 // mid <= r
+        int64_t nn, nl;
+        bn_counts(C, mid, r, nn, nl);
+        if (C.W[mid] >= bn_cost(C, mid, r, nn, nl)) hi = mid; else lo = mid + 1;
+    }
+    int64_t nn = 0, nl = 0;
+    if (lo <= r) bn_counts(C, lo, r, nn, nl);
+    c0[t] = (int32_t)lo; nn0[t] = (int32_t)nn; nl0[t] = (int32_t)nl;
+}
+
+// one lane per chunk: the two-pointer walk
+template <typename TC>
+__global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk,
+                                                 const int32_t *__restrict__ c0, const int32_t *__restrict__ nn0, const int32_t *__restrict__ nl0,
+                                                 const int32_t *__restrict__ runend, TC *__restrict__ cst, int32_t *__restrict__ ptr)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunk) return;
+    const int32_t r0 = (int32_t)(rlo + t * CH);
+    int32_t r1 = (int32_t)(r0 + CH - 1);
+    if (r1 > rhi) r1 = (int32_t)rhi;
+    int32_t c = c0[t], nn = nn0[t], nl = nl0[t];
+    const bool nets = C.M.kind != CP_MODEL_WORK;
+    for (int32_t r = r0; r <= r1; r++) {
+        if (r > r0) {
+            // column r - 1 joins the part [c, r - 1) on the right (an empty part stays empty when c == r)
+            if (c <= r - 1) {
+                if (nets) for (int32_t q = C.pos32[r - 1], q1 = C.pos32[r]; q < q1; q++) nn += (C.prev[q] < c);
+                if (C.hyp) for (int32_t q = C.lpos32[r - 1], q1 = C.lpos32[r]; q < q1; q++) nl += (C.lfirst[q] >= c);
+            }
+            // the crossing only moves right
+            while (c <= r) {
+                if (!(C.W[c] < bn_cost(C, c, r, nn, nl))) break;
+                if (c < r) {                                // column c leaves on the left
+                    if (nets) for (int32_t q = C.pos32[c], q1 = C.pos32[c + 1]; q < q1; q++) nn -= (C.next[q] >= r);
+                    if (C.hyp) for (int32_t q = C.fpos32[c], q1 = C.fpos32[c + 1]; q < q1; q++) nl -= (C.flast[q] < r);
+                }
+                c++;
+            }
+            if (c > r) { nn = 0; nl = 0; }
+        }
+        // f(c - 1, r): column c - 1 joins on the left
+        bool have_fm = c >= 1;
+        TC fm = (TC)0;
+        if (have_fm) {
+            int32_t a = 0, al = 0;
+            if (c - 1 < r) {
+                a = nn; al = nl;
+                if (nets) for (int32_t q = C.pos32[c - 1], q1 = C.pos32[c]; q < q1; q++) a += (C.next[q] >= r);
+                if (C.hyp) for (int32_t q = C.fpos32[c - 1], q1 = C.fpos32[c]; q < q1; q++) al += (C.flast[q] < r);
+            }
+            fm = bn_cost(C, c - 1, r, a, al);
+        }
+        TC v; int32_t p;
+        if (c <= r && (!have_fm || C.W[c] <= fm)) { v = C.W[c]; p = runend[c] < r ? runend[c] : r; }
+        else { v = fm; p = c - 1; }
+        cst[r] = v; ptr[r] = p;
+    }
+}
+
+struct BnWork {
+    bool have_net = false, have_self = false;
+    WaveletHost net, self;
+    DBuf<int32_t> runend, blk, c0, nn0, nl0;
+};
+
+static BnWork *bn_work_get(cp_csr_s *A)
+{
+    if (!A->bn_work) {
+        A->bn_work = new BnWork();
+        A->bn_work_free_fn = [](void *w) { delete reinterpret_cast<BnWork *>(w); };
+        A->bn_work_reset_fn = [](void *w) { auto *B = reinterpret_cast<BnWork *>(w); B->have_net = false; B->have_self = false; };   // (cp_csr_reset_cache)
+    }
+    return reinterpret_cast<BnWork *>(A->bn_work);
+}
+
+int64_t g_opt_bn_chunk = 128;
+
+template <typename TC>
+void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
+                         int64_t rlo, int64_t rhi)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n, n1 = n + 1;
+    if (rhi < rlo) return;
+    BnWork *B = bn_work_get(A);
+    const bool hyp = M.kind == CP_MODEL_HYPEREDGE_CUT;
+    ensure_links(A);
+    if (hyp) ensure_self(A);
+    if (M.kind != CP_MODEL_WORK && !B->have_net) { ProfScope ps(PROF_WAVELET, s, 0.0); ensure_net_counter(A, B->net); B->have_net = true; }
+    if (hyp && !B->have_self) { ProfScope ps(PROF_WAVELET, s, 0.0); ensure_selfnet_counter(A, B->self); B->have_self = true; }
+    BnCtx<TC> C;
+    C.M = M; C.alpha = alpha; C.n = n; C.hyp = hyp ? 1 : 0;
+    C.pos = A->pos.p; C.lpos = hyp ? A->lpos.p : nullptr;
+    C.pos32 = A->pos32.p; C.prev = A->prev.p; C.next = A->next.p;
+    C.fpos32 = hyp ? A->fpos32.p : nullptr; C.flast = hyp ? A->flast.p : nullptr;
+    C.lpos32 = hyp ? A->lpos32.p : nullptr; C.lfirst = hyp ? A->lfirst.p : nullptr;
+    C.net = B->net.d; C.self = B->self.d; C.W = W;
+    const int64_t nblk = cdiv(n1, 1024);
+    B->runend.ensure((size_t)n1); B->blk.ensure((size_t)nblk + 1);
+    const int64_t CH = std::max<int64_t>(1, g_opt_bn_chunk), nchunk = cdiv(rhi - rlo + 1, CH);
+    B->c0.ensure((size_t)nchunk); B->nn0.ensure((size_t)nchunk); B->nl0.ensure((size_t)nchunk);
+    ProfScope ps(PROF_BRUTE, s, 8.0 * (double)A->N + 24.0 * (double)(rhi - rlo + 1));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_run1<TC>), dim3((unsigned)nblk), dim3(1024), 0, s, n1, W, B->runend.p, B->blk.p);
+    hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1), 0, s, nblk, B->blk.p);
+    hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
+                       B->runend.p, cst_out, ptr_out);
+    CP_HIP(hipGetLastError());
+}
+
+template void dp_bottleneck_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, int64_t, int64_t);
+template void dp_bottleneck_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, int64_t, int64_t);
+
+}  // namespace cpk
