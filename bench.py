@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the partition_stripe hot path on MI355X.
+"""bench.py -- benchmarks of the partition_stripe / pack_stripe hot path on MI355X.
 
-Workload (BASELINE.json configs[2]): DynamicTotalSplitter +
-AffineConnectivityModel{Int64}(0,0,0,1), K = 64, on a synthetic `suitesparse_shaped` pattern with
-n = m = 10^7 columns and N = 10^8 nonzeros.  One "step" = one full partition_stripe call INCLUDING
-oracle construction (link arrays), with colptr/rowval already resident in HBM (what the reference's
-`@benchmarkable partition_stripe($A,$K,$f)` times, test/runbenchmarks.jl:65).
+  python bench.py [--config C] --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+Configs (every matrix comes from the seeded SplitMix64 generator tests/synth.py, base seed 0xDEADBEEF +
+config index; one "step" = one full partition call INCLUDING oracle construction, colptr / rowval already resident in HBM --
+what the reference's `@benchmarkable partition_stripe($A,$K,$f)` times, test/runbenchmarks.jl:65):
+
+  3 (default, the metric of BASELINE.json)  DynamicTotalSplitter(AffineConnectivityModel{Int64}(0,0,0,1)), K = 64, on
+              suitesparse_shaped n = m = 10^7, nnz = 10^8.  Its answer is closed-form ([1, n+1, ..., n+1]: for every cost the
+              O(n log^2 n) path admits the diagonal candidate ties the minimum); all K layers are computed.
+  constrained DynamicTotalSplitter(ConstrainedCost(the same cost, VertexCount(), ceil(1.5 n / K))) -- the reference's own script
+              (bin/test_table_constrained_splits.jl:28) -- on the same matrix: a non-trivial answer on the windowed path.
+  bottleneck  DynamicBottleneckSplitter(AffineConnectivityModel(0,10,1,100)), K = 64, same matrix; cross-checked at full size
+              against BisectIndexBottleneckSplitter (exact).
+  2           BisectCostBottleneckSplitter(AffineWorkModel(0,10,1) / AffineConnectivityModel(0,10,1,100), 0.01), n = 10^6, K = 32.
+  4           ConvexTotalChunker / DynamicTotalChunker(ConstrainedCost(ColumnBlockComponentCostModel{Int}(3, w->1+w),
+              VertexCount(), 8)) on banded n = 5*10^6 (test/runbenchmarks.jl:21,31-33), the oracle timed beside it at full size.
+  5shape      DynamicTotalSplitter(AffineHyperedgeCutModel(0,0,0,0,1)) on n = 5*10^7, nnz = 5*10^8 on ONE GPU (config 5 is the
+              8-GPU row-tiled run of the same shape: --config 5shape --mode tiled under torch.distributed.run).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the dominant kernel (dp_lpass), HIP-event timed inside the timed region
-  cpu_baseline : the literal CPU restatement (oracle/, kind "port", 1 core) on a bounded sample,
-                 extrapolated by t = a*K*n^2 because the literal sweep cannot run at n = 10^7.
+  roofline     : the dominant kernel, HIP-event timed inside the timed region, against the 8 TB/s HBM peak
+  cpu_baseline : the literal CPU restatement (oracle/, kind "port", 1 core) on a bounded sample
+and, for the default config, `extras.other_configs`: short runs of `constrained`, `bottleneck` and `2`, the time with the
+host-to-device copy of the pattern, and the second CPU baseline (the oracle's ConvexTotalSplitter).
 """
 import argparse
 import json
@@ -21,68 +33,28 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [ROOT]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 import numpy as np
 import torch
 
 import cpamd
+import synth
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec HBM3E peak, MI355X_MICROARCH.md "Chip-level parameters"
+SEED = 0xDEADBEEF
 
 
 def gen_suitesparse_shaped(n, N, seed, device):
-    """`suitesparse_shaped`: lognormal column degrees (sigma = 1) clipped to [1, 10^4],
-    80 % of a column's rows ~ N(j, (n/100)^2), 20 % uniform; rows sorted + deduplicated per column;
-    trimmed to exactly N nonzeros.  Returns 1-based int64 colptr / rowval tensors on `device`."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    m = n
-    mean_deg = N / n
-    mu = np.log(mean_deg * 1.08) - 0.5           # lognormal mean = exp(mu + 1/2); 8 % head-room for duplicates/trim
-    deg = torch.exp(torch.randn(n, generator=g, device=device) + mu).round().clamp_(1, 10000).to(torch.int64)
-    cols = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
-    tot = cols.numel()
-    local = torch.rand(tot, generator=g, device=device) < 0.8
-    rows = torch.where(local,
-                       (cols.to(torch.float64) + torch.randn(tot, generator=g, device=device, dtype=torch.float64) * (n / 100.0)).round(),
-                       torch.randint(0, m, (tot,), generator=g, device=device).to(torch.float64))
-    rows = rows.clamp_(0, m - 1).to(torch.int64)
-    key = torch.unique(cols * m + rows)          # sorted (column-major, rows ascending), duplicates removed
-    del cols, rows, local
-    if key.numel() > N:                          # trim uniformly at random, keep order
-        keep = torch.randperm(key.numel(), generator=g, device=device)[:N]
-        key = key[torch.sort(keep).values]
-    cols = key // m
-    rowval = (key % m) + 1
-    cnt = torch.bincount(cols, minlength=n)
-    colptr = torch.cat([torch.ones(1, dtype=torch.int64, device=device), 1 + torch.cumsum(cnt, 0)])
-    return colptr.contiguous(), rowval.contiguous()
+    """`suitesparse_shaped` (tests/synth.py) trimmed to exactly N nonzeros: 1-based int64 colptr / rowval on `device`"""
+    _, _, colptr, rowval = synth.suitesparse_shaped_t(n, N / n, seed, device, nnz=N)
+    return colptr, rowval
 
 
-def cpu_baseline(K, mean_deg, budget_s=25.0):
-    """Literal restatement (oracle/liborc.so, 1 core) of DynamicTotalSplitter on the same generator at
-    small n; fit t = a*K*n^2 and extrapolate to the headline n (SURVEY.md 8d "CPU baseline")."""
-    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+def oracle_backend():
+    sys.path[:0] = [os.path.join(ROOT, "oracle")]
     import orc_binding
-    cp = cpamd.load()
-    orc = orc_binding.OracleBackend()
-    mdl = cp.AffineConnectivityModel(0, 0, 0, 1)
-    samples = []
-    t_used = 0.0
-    for n in (4000, 8000, 16000):
-        colptr, rowval = gen_suitesparse_shaped(n, int(n * mean_deg), 0xDEADBEEF + 3, "cpu")
-        A = cp.SparseMatrixCSC(n, n, colptr.numpy(), rowval.numpy())
-        est = samples[-1][1] * 4 if samples else 0.0
-        if t_used + est > budget_s:
-            break
-        t0 = time.perf_counter()
-        cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=orc)
-        dt = time.perf_counter() - t0
-        samples.append((n, dt))
-        t_used += dt
-    a = float(np.mean([dt / (K * n * n) for n, dt in samples]))
-    return a, samples
+    return orc_binding.OracleBackend()
 
 
 def measure_copy_gbs(dev):
@@ -102,19 +74,355 @@ def measure_copy_gbs(dev):
     return 2.0 * (1 << 30) / (ms * 1e-3) / 1e9
 
 
+def timed(f, reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines (oracle, 1 core)
+def cpu_fit_quadratic(make_method, K, mean_deg, seed, sizes=(4000, 8000, 16000), budget_s=25.0, per_k=True):
+    """the literal O(n^2)-per-layer sweeps cannot run at bench size: time them at small n on the same generator, fit
+    t = a * [K *] n^2 and extrapolate"""
+    cp = cpamd.load()
+    orc = oracle_backend()
+    samples, used = [], 0.0
+    for n in sizes:
+        est = samples[-1][1] * 4 if samples else 0.0
+        if used + est > budget_s:
+            break
+        _, _, colptr, rowval = synth.suitesparse_shaped_np(n, mean_deg, seed, nnz=int(n * mean_deg))
+        A = cp.SparseMatrixCSC(n, n, colptr, rowval)
+        t0 = time.perf_counter()
+        cp.partition_stripe(A, K, make_method(cp, n), backend=orc)
+        dt = time.perf_counter() - t0
+        samples.append((n, dt)); used += dt
+    a = float(np.mean([dt / ((K if per_k else 1) * n * n) for n, dt in samples]))
+    return a, samples
+
+
+def cpu_convex_splitter(K, mean_deg, seed, n=100_000):
+    """SURVEY 8(d) second baseline: the oracle's ConvexTotalSplitter -- the reference's own fastest exact-value method for this
+    cost -- timed directly at the largest n that fits the budget"""
+    cp = cpamd.load()
+    orc = oracle_backend()
+    _, _, colptr, rowval = synth.suitesparse_shaped_np(n, mean_deg, seed, nnz=int(n * mean_deg))
+    A = cp.SparseMatrixCSC(n, n, colptr, rowval)
+    t0 = time.perf_counter()
+    cp.partition_stripe(A, K, cp.ConvexTotalSplitter(cp.AffineConnectivityModel(0, 0, 0, 1)), backend=orc)
+    return n, time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------ the DP configs on one matrix
+class DpBench:
+    """config 3 / constrained / bottleneck / 5shape: K-part DP on a suitesparse_shaped pattern resident in HBM"""
+
+    def __init__(self, args, cfg, dev, rank, world, tiled):
+        self.cp = cpamd.load()
+        from chainpartitioners_jl_amd import _lib
+        self.hip = _lib.HipBackend(device=dev.index)
+        self.args, self.cfg, self.dev, self.tiled = args, cfg, dev, tiled
+        big = cfg == "5shape"
+        self.n = args.n or (50_000_000 if big else 10_000_000)
+        N = args.nnz or (500_000_000 if big else 100_000_000)
+        self.K = args.parts or 64
+        seed = SEED + (5 if big else 3) - 1 + (0 if tiled else 1000 * rank)      # config index; independent partitions: one matrix per rank
+        self.colptr, self.rowval = gen_suitesparse_shaped(self.n, N, seed, dev)
+        self.N = int(self.rowval.numel())
+        torch.cuda.synchronize()
+        self.h = self.hip.csr_from_device(self.n, self.n, self.N, self.colptr.data_ptr(), self.rowval.data_ptr())
+        cp = self.cp
+        self.combine, self.wm, self.w = 0, None, 0
+        if cfg in ("3", "constrained"):
+            self.mdl = cp.AffineConnectivityModel(0, 0, 0, 1); self.mname = "AffineConnectivityModel{Int64}(0,0,0,1)"
+        elif cfg == "bottleneck":
+            self.mdl = cp.AffineConnectivityModel(0, 10, 1, 100); self.mname = "AffineConnectivityModel{Int64}(0,10,1,100)"; self.combine = 1
+        else:
+            self.mdl = cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1); self.mname = "AffineHyperedgeCutModel{Int64}(0,0,0,0,1)"
+        if cfg == "constrained":
+            self.wm = cp.VertexCount().marshal(); self.w = -(-3 * self.n // (2 * self.K))
+        self.mm = self.mdl.marshal()
+        self.spl = np.zeros(self.K + 1, dtype=np.int64)
+
+    def method_name(self):
+        if self.cfg == "constrained":
+            return "DynamicTotalSplitter(ConstrainedCost(%s, VertexCount(), %d))" % (self.mname, self.w)
+        return ("DynamicBottleneckSplitter(%s)" if self.combine else "DynamicTotalSplitter(%s)") % self.mname
+
+    def step(self):
+        hip, h = self.hip, self.h
+        hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does
+        if self.tiled:
+            from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
+            meth = self.cp.DynamicBottleneckSplitter(self.mdl) if self.combine else self.cp.DynamicTotalSplitter(self.mdl)
+            self.spl[:] = partition_stripe_tiled(hip, h, self.n, self.K, meth, device=self.dev)
+            return
+        rc = hip.partition_dynamic(h, self.K, self.combine, 0, self.mm, None, self.wm, self.w, float(self.w), self.spl)
+        if rc != 0:
+            raise RuntimeError(f"cp_partition_dynamic -> {rc}: {hip.last_error()}")
+
+    def check(self):
+        """size-independent properties at full size (bit-exact parity itself is established by tests/ at oracle sizes)"""
+        n, K, spl, hip = self.n, self.K, self.spl, self.hip
+        assert spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0), spl
+        rc, obj = hip.objective(self.h, K, spl, self.mm, None, self.combine)
+        assert rc == 0
+        rc, whole = hip.objective(self.h, 1, np.array([1, n + 1], dtype=np.int64), self.mm, None, self.combine)
+        info = {"objective": int(obj)}
+        if self.cfg == "constrained":
+            assert int(np.diff(spl).max()) <= self.w                         # every part respects w_max
+            equi = np.minimum(1 + self.w * np.arange(K + 1, dtype=np.int64), n + 1)      # a feasible partition: greedy full-width parts
+            rc, obj_eq = hip.objective(self.h, K, equi, self.mm, None, 0)
+            assert obj <= obj_eq                                              # the optimum is no worse than a feasible partition
+            info.update({"max_width": int(np.diff(spl).max()), "w_max": int(self.w), "nonempty_parts": int((np.diff(spl) > 0).sum()),
+                         "objective_of_full_width_parts": int(obj_eq)})
+        elif self.combine:
+            bi = np.zeros(K + 1, dtype=np.int64)
+            rc = hip.partition_bisect_index(self.h, K, self.mm, 0, bi)
+            assert rc == 0
+            rc, obj_bi = hip.objective(self.h, K, bi, self.mm, None, 1)
+            assert obj == obj_bi, (obj, obj_bi)                               # the DP optimum == the exact BisectIndex optimum
+            info["bisect_index_bottleneck"] = int(obj_bi)
+        else:
+            assert obj >= whole                                               # sum_k nets_k >= nets(all columns)
+        return info
+
+
+def run_dp(args, cfg, dev, rank, world, dist):
+    tiled = args.mode == "tiled" and world > 1
+    B = DpBench(args, cfg, dev, rank, world, tiled)
+    hip, n, N, K = B.hip, B.n, B.N, B.K
+    for kv in args.opt:
+        name, val = kv.split("=")
+        assert hip.set_option(name, int(val)) == 0, kv
+    copy_gbs = measure_copy_gbs(dev)
+    # The per-kernel breakdown (HIP events around every launch group: ~40 records per DP round) is taken on an UNTIMED step; the
+    # timed region keeps events around the dominant kernel only (2 per round), as the roofline line needs them live.
+    for _ in range(max(args.warmup - 1, 0)):
+        B.step()
+    hip.prof_reset(); hip.prof_enable(True)
+    B.step()
+    torch.cuda.synchronize()
+    prof_all = hip.prof_get()
+    slots = list(prof_all.keys())
+    cands = (("dp_lpass_own", "k_lpass_own"), ("dp_lpass", "k_lpass"), ("dp_brute", "k_bn_walk"))
+    dom, kname = max(cands, key=lambda kv: prof_all.get(kv[0], {"ms": 0.0})["ms"])
+    hip.prof_reset()
+    assert hip.set_option("prof_only", slots.index(dom)) == 0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        B.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    hip.prof_enable(False)
+    hip.set_option("prof_only", -1)
+    prof = hip.prof_get()
+    spl_t = torch.from_numpy(B.spl.copy()).to(dev)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        gathered = [torch.empty_like(spl_t) for _ in range(world)]      # the K+1-entry split vectors of all ranks: one RCCL all_gather
+        dist.all_gather(gathered, spl_t)
+    info = B.check()
+    if rank != 0:
+        return None
+    ms_per_step = dt / args.steps * 1e3
+    value = (1 if tiled else world) * args.steps / dt
+    ex = prof[dom]
+    bytes_per_launch = ex["units"] / max(ex["launches"], 1)       # accumulated by the library per launch (DESIGN.md section 6)
+    avg_ms = ex["ms"] / max(ex["launches"], 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    b_alg = 8.0 * (n + 1 + N) + K * (n + 1) * 24.0 + 8.0 * (K + 1)      # SURVEY.md 8(d) whole-partition bytes
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % kname)
+    if cfg == "3" and os.path.exists(pmc_path) and (n, N) == (10_000_000, 100_000_000):
+        traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
+    out = {
+        "metric": "partitions/sec, %s, K=%d" % (B.method_name(), K),
+        "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
+        "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "config %s: %s on suitesparse_shaped CSR (seeded SplitMix64 generator, tests/synth.py), n=%d rows, nnz=%d, K=%d; %s"
+                               % (cfg, B.method_name(), n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
+                   "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
+        "roofline": {"bound": "hbm", "kernel": "%s (%s)" % (dom, kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_copy_gbs": copy_gbs,      # this box's device-to-device copy rate (read + write bytes), SURVEY 8(d)
+                     "avg_launch_ms": avg_ms, "launches_per_step": ex["launches"] / args.steps,
+                     "alg_bytes_per_launch": bytes_per_launch,
+                     "whole_path": {"alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9,
+                                    "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]},      # from the untimed profiling step
+        "check": info,
+        "extras": {},
+    }
+    if cfg == "3":
+        out["extras"]["closed_form_note"] = ("for every cost this path admits, ptr[j',k] = j' and spl = [1, n+1, ..., n+1] (DESIGN.md section 4): "
+                                             "`value` times all K layers; the layer kernels are checked with injected previous rows (tests/test_gpu_blocks.py)")
+        if not tiled:
+            # untimed extras, never part of `value`
+            assert hip.set_option("fixed_point", 1) == 0
+            keep = B.spl.copy()
+            out["extras"]["ms_per_step_with_fixed_point_exit"] = timed(B.step, 1) * 1e3
+            hip.set_option("fixed_point", 0)
+            assert np.array_equal(B.spl, keep), "fixed-point exit changed the partition"
+            # the same call with the pattern in host memory: cp_csr_create copies colptr / rowval over PCIe first
+            hc, hr = B.colptr.cpu().numpy(), B.rowval.cpu().numpy()
+            A_host = B.cp.SparseMatrixCSC(n, n, hc, hr)
+
+            def with_h2d():
+                meth = B.cp.DynamicTotalSplitter(B.mdl)
+                B.cp.partition_stripe(A_host, K, meth, backend=hip)
+            out["extras"]["ms_per_step_with_h2d"] = timed(with_h2d, 1) * 1e3
+            del A_host, hc, hr
+    if not args.no_cpu_baseline:
+        avg_deg = N / n
+        if cfg in ("3", "5shape", "bottleneck"):
+            mk = (lambda cp, nn: cp.DynamicBottleneckSplitter(B.mdl)) if B.combine else (lambda cp, nn: cp.DynamicTotalSplitter(B.mdl))
+            a, samples = cpu_fit_quadratic(mk, K, avg_deg, SEED + 2)
+            t_full = a * K * float(n) * float(n)
+            law = "t = a*K*n^2 with a=%.3e s" % a
+        else:
+            mk = lambda cp, nn: cp.DynamicTotalSplitter(cp.ConstrainedCost(B.mdl, cp.VertexCount(), -(-3 * nn // (2 * K))))
+            a, samples = cpu_fit_quadratic(mk, K, avg_deg, SEED + 2, per_k=False)
+            t_full = a * float(n) * float(n)
+            law = "t = a*n^2 (the windows make the work independent of K) with a=%.3e s" % a
+        out["cpu_baseline"] = {"value": 1.0 / t_full, "unit": "partitions/s", "cores": 1, "kind": "port",
+                               "sample": "literal restatement of %s timed at n=%s (K=%d, same generator), %s extrapolated to n=%d"
+                                         % (B.method_name(), [s[0] for s in samples], K, law, n),
+                               "sample_seconds": [s[1] for s in samples], "host_cores": os.cpu_count()}
+    return out, B
+
+
+# ------------------------------------------------------------------------------------------------ config 2
+def run_cfg2(args, dev, brief=False):
+    cp = cpamd.load()
+    from chainpartitioners_jl_amd import _lib
+    hip = _lib.HipBackend(device=dev.index)
+    n = args.n or 1_000_000
+    K = args.parts or 32
+    _, _, colptr, rowval = synth.suitesparse_shaped_t(n, 13, SEED + 1, dev, nnz=13 * n)
+    N = int(rowval.numel())
+    h = hip.csr_from_device(n, n, N, colptr.data_ptr(), rowval.data_ptr())
+    spl = np.zeros(K + 1, dtype=np.int64)
+    res = {}
+    for name, mdl in (("work", cp.AffineWorkModel(0, 10, 1)), ("connectivity", cp.AffineConnectivityModel(0, 10, 1, 100))):
+        mm = mdl.marshal()
+
+        def run():
+            hip.reset_cache(h)
+            rc = hip.partition_bisect_cost(h, K, mm, 0.01, 0, spl)
+            assert rc == 0, hip.last_error()
+        run()
+        t = timed(run, max(args.steps, 3))
+        rc, obj = hip.objective(h, K, spl, mm, None, 1)
+        rc, lo, hi = hip.bound_stripe(h, K, mm)
+        assert lo <= obj <= hi                                               # the bounds sandwich of test_Costs.jl
+        res[name] = {"ms_per_step": t * 1e3, "bottleneck": int(obj), "bound_stripe": [int(lo), int(hi)]}
+    hip.csr_destroy(h)
+    info = {"n": n, "nnz": N, "K": K, "eps": 0.01, "results": res}
+    if brief:
+        return info
+    # CPU baseline: the oracle's BisectCost directly at full size (SURVEY 8d-3)
+    out = {"metric": "partitions/sec, BisectCostBottleneckSplitter(AffineConnectivityModel{Int64}(0,10,1,100), 0.01), K=%d" % K,
+           "value": 1e3 / res["connectivity"]["ms_per_step"], "unit": "partitions/s", "n_gpus": 1, "steps": max(args.steps, 3), "warmup": 1,
+           "ms_per_step": res["connectivity"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": "config 2: BisectCostBottleneckSplitter on suitesparse_shaped CSR, n=%d, nnz=%d, K=%d, eps=0.01 (includes link-array + counter build)" % (n, N, K)},
+           "roofline": {"bound": "hbm", "kernel": "k_bisect (one wave: latency-bound probe chain; roofline N/A, SURVEY 8d)", "achieved": 8.0 * (n + 1 + N) / (res["connectivity"]["ms_per_step"] * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * (n + 1 + N) / (res["connectivity"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+           "check": info}
+    if not args.no_cpu_baseline:
+        orc = oracle_backend()
+        A = cp.SparseMatrixCSC(n, n, colptr.cpu().numpy(), rowval.cpu().numpy())
+        t0 = time.perf_counter()
+        P = cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(cp.AffineConnectivityModel(0, 10, 1, 100), 0.01), backend=orc)
+        tc = time.perf_counter() - t0
+        assert np.array_equal(P.spl, spl), "GPU and oracle split vectors differ at full size"
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "partitions/s", "cores": 1, "kind": "port",
+                               "sample": "the oracle's BisectCost at the full size n=%d (direct; same split vector as the GPU)" % n, "host_cores": os.cpu_count()}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+def run_cfg4(args, dev):
+    cp = cpamd.load()
+    from chainpartitioners_jl_amd import _lib
+    hip = _lib.HipBackend(device=dev.index)
+    n = args.n or 5_000_000
+    _, _, colptr, rowval = synth.banded_t(n, 16, 0.5, SEED + 4, dev)
+    N = int(rowval.numel())
+    h = hip.csr_from_device(n, n, N, colptr.data_ptr(), rowval.data_ptr())
+    colb = cp.ColumnBlockComponentCostModel(3, lambda w: 1 + w)
+    f = cp.ConstrainedCost(colb, cp.VertexCount(), 8)
+    import types
+    from chainpartitioners_jl_amd import api
+    proxy = types.SimpleNamespace(n=n, m=n)             # (the closure w -> 1 + w is tabulated for the widths a method evaluates)
+    mms = {"convex": api._marshal(proxy, f, None, stack_method=True), "dynamic": api._marshal(proxy, f, None)}
+    out_spl = {}
+    times = {}
+    for name in ("convex", "dynamic"):
+        spl = np.zeros(n + 2, dtype=np.int64); Kout = np.zeros(1, dtype=np.int64)
+        _, mm, wm, wi, wf, _, _keep = mms[name]
+
+        def run():
+            hip.reset_cache(h)
+            rc = (hip.pack_convex if name == "convex" else hip.pack_dynamic)(h, mm, None, wm, wi, wf, spl, Kout)
+            assert rc == 0, hip.last_error()
+        run()
+        times[name] = timed(run, max(1, args.steps if name == "dynamic" else 1))
+        out_spl[name] = spl[:int(Kout[0]) + 1].copy()
+        assert int(np.diff(out_spl[name]).max()) <= 8
+    value = {}
+    mm_obj = api._marshal(proxy, colb, None)[1]
+    for name in ("convex", "dynamic"):
+        s = out_spl[name]
+        rc, v = hip.objective(h, len(s) - 1, s, mm_obj, None, 0)
+        assert rc == 0, hip.last_error()
+        value[name] = int(v)
+    assert value["dynamic"] <= value["convex"]          # the DP is optimal; the convex chunker is a heuristic on this non-Monge cost
+    out = {"metric": "partitions/sec, pack_stripe(ConvexTotalChunker(ConstrainedCost(ColumnBlockComponentCostModel{Int}(3, w->1+w), VertexCount(), 8)))",
+           "value": 1.0 / times["convex"], "unit": "partitions/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": times["convex"] * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "config": {"workload": "config 4: ConvexTotalChunker + ColumnBlock cost, w_max=8, banded n=%d (half bandwidth 16, fill 0.5), nnz=%d; includes link arrays + window table" % (n, N)},
+           "roofline": {"bound": "hbm", "kernel": "k_pack_convex_win (one wave, sequential by the algorithm: latency-bound)",
+                        "achieved": (8.0 * (n + 1 + N) + 24.0 * (n + 1)) / times["convex"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (8.0 * (n + 1 + N) + 24.0 * (n + 1)) / times["convex"] / 1e9 / HBM_PEAK_GBS, "traffic": None},
+           "check": {"K_convex": len(out_spl["convex"]) - 1, "K_dynamic": len(out_spl["dynamic"]) - 1, "total_value": value,
+                     "dynamic_total_chunker_ms": times["dynamic"] * 1e3}}
+    if not args.no_cpu_baseline:
+        orc = oracle_backend()
+        A = cp.SparseMatrixCSC(n, n, colptr.cpu().numpy(), rowval.cpu().numpy())
+        t0 = time.perf_counter()
+        P = cp.pack_stripe(A, cp.ConvexTotalChunker(f), backend=orc)
+        tc = time.perf_counter() - t0
+        assert np.array_equal(P.spl, out_spl["convex"]), "GPU and oracle chunk vectors differ at full size"
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "partitions/s", "cores": 1, "kind": "port", "seconds": tc,
+                               "sample": "the oracle's ConvexTotalChunker at the full size n=%d (direct; identical chunk vector)" % n, "host_cores": os.cpu_count()}
+    hip.csr_destroy(h)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="3", choices=["3", "constrained", "bottleneck", "2", "4", "5shape"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--nnz", type=int, default=100_000_000)
-    ap.add_argument("--parts", type=int, default=64)
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--nnz", type=int, default=0)
+    ap.add_argument("--parts", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["connectivity", "hyperedge"], default="connectivity",
-                    help="connectivity = BASELINE config 3 (default, the metric); hyperedge = the config-5 cost "
-                         "AffineHyperedgeCutModel(0,0,0,0,1) for scale checks")
-    ap.add_argument("--dbg", type=int, default=0, help="timing experiments only (wrong results)")
+    ap.add_argument("--no-extras", action="store_true", help="config 3: skip the short runs of the other configs")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (cp_set_option), e.g. short_t=4")
     ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
                     help="N>1: 'independent' = one partition per GPU (weak scaling, default); 'tiled' = ONE partition whose DP rows "
@@ -134,144 +442,37 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
-    cp = cpamd.load()
-    from chainpartitioners_jl_amd import _lib
-    hip = _lib.HipBackend(device=dev.index)
-    n, N, K = args.n, args.nnz, args.parts
-    # independent partitions shard across ranks (weak scaling): every rank owns one matrix of the same shape
-    tiled = args.mode == "tiled" and world > 1
-    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 2 + (0 if tiled else 1000 * rank), dev)
-    N = int(rowval.numel())
-    torch.cuda.synchronize()
-    h = hip.csr_from_device(n, n, N, colptr.data_ptr(), rowval.data_ptr())
-    mdl = cp.AffineConnectivityModel(0, 0, 0, 1) if args.model == "connectivity" else cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1)
-    mm = mdl.marshal()
-    spl = np.zeros(K + 1, dtype=np.int64)
-    if args.dbg:
-        hip.set_option("dbg", args.dbg)
-    for kv in args.opt:
-        name, val = kv.split("=")
-        assert hip.set_option(name, int(val)) == 0, kv
-
-    def step():
-        hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does
-        if tiled:
-            from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
-            spl[:] = partition_stripe_tiled(hip, h, n, K, cp.DynamicTotalSplitter(mdl), device=dev)
-            return
-        rc = hip.partition_dynamic(h, K, 0, 0, mm, None, None, 0, 0.0, spl)
-        if rc != 0:
-            raise RuntimeError(f"cp_partition_dynamic -> {rc}: {hip.last_error()}")
-
-    # The per-kernel breakdown (HIP events around every launch group: ~40 records per DP round) is taken on an UNTIMED step;
-    # the timed region keeps events around the dominant kernel only (2 per round), as the roofline line needs them live.
-    copy_gbs = measure_copy_gbs(dev)
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
-    hip.prof_reset()
-    hip.prof_enable(True)
-    step()
-    torch.cuda.synchronize()
-    prof_all = hip.prof_get()
-    slots = list(prof_all.keys())
-    dom, kname = max((("dp_lpass_own", "k_lpass_own"), ("dp_lpass", "k_lpass")), key=lambda kv: prof_all.get(kv[0], {"ms": 0.0})["ms"])
-    hip.prof_reset()
-    assert hip.set_option("prof_only", slots.index(dom)) == 0
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    hip.prof_enable(False)
-    prof = hip.prof_get()
-    # Untimed extra, never part of `value`: the same call with cp_set_option("fixed_point", 1).  For this model (alpha = 0: empty
-    # parts are free) the cost row stops changing after layer 2, and the exact early exit copies the remaining layers.
-    fp_ms = None
-    if not tiled and not args.dbg:
-        assert hip.set_option("fixed_point", 1) == 0
-        spl_keep = spl.copy()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        fp_ms = (time.perf_counter() - t1) * 1e3
-        hip.set_option("fixed_point", 0)
-        assert np.array_equal(spl, spl_keep), "fixed-point exit changed the partition"
-
-    # split vectors of all ranks are exchanged with one RCCL all_gather (K+1 int64 per rank)
-    spl_t = torch.from_numpy(spl.copy()).to(dev)
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        gathered = [torch.empty_like(spl_t) for _ in range(world)]
-        dist.all_gather(gathered, spl_t)
-
-    # size-independent checks at full size: structure + objective consistency (bit-exact parity itself is
-    # established by tests/ at sizes the oracle can run)
-    assert args.dbg or (spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0)), spl
-    rc, obj = hip.objective(h, K, spl, mm, None, 0)
-    assert rc == 0
-    one = np.array([1, n + 1], dtype=np.int64)
-    rc, whole = hip.objective(h, 1, one, mm, None, 0)
-    assert args.dbg or obj >= whole          # sum_k nets_k >= nets(all columns): coverage is subadditive
-
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = (1 if tiled else world) * args.steps / dt
-        # the dominant kernel: the left-part pass over the long tasks with tiles of their own (k_lpass_own) -- or, if it ever
-        # took longer, the pass over the flattened medium tasks (k_lpass)
-        ex = prof[dom]
-        avg_deg = N / n
-        # algorithmic bytes of one launch, accumulated by the library per launch:
-        # per left step the stepped column's link entries (4 B x N/n), its colptr entry (8 B), the
-        # candidate's previous-layer cost (8 B) and the task-descriptor share (8 B)
-        bytes_per_launch = ex["units"] / max(ex["launches"], 1)
-        avg_ms = ex["ms"] / max(ex["launches"], 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        b_alg = 8.0 * (n + 1 + N) + K * (n + 1) * 24.0 + 8.0 * (K + 1)      # SURVEY.md 8(d) whole-partition bytes
-        # HBM traffic of the dominant kernel from the PMC counters: collected by tools/pmc_lpass.sh under rocprofv3
-        # (FETCH_SIZE and WRITE_SIZE in separate passes) and committed under profiles/; valid for the default workload only
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01e_pmc_%s.json" % kname)
-        if os.path.exists(pmc_path) and (n, args.nnz) == (10_000_000, 100_000_000):
-            traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
-        out = {
-            "metric": "partitions/sec, DynamicTotalSplitter(%s), K=%d"
-                      % ("AffineConnectivityModel{Int64}(0,0,0,1)" if args.model == "connectivity" else "AffineHyperedgeCutModel{Int64}(0,0,0,0,1)", K),
-            "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if tiled else "weak", "vs_baseline": None,
-            "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "DynamicSplitter + %s on suitesparse_shaped CSR, "
-                                   "n=%d rows, nnz=%d, K=%d; %s" % ("ConnectivityCosts (lambda-1)" if args.model == "connectivity" else "HyperedgeCutCosts (cut nets)", n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
-                       "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
-            "roofline": {"bound": "hbm", "kernel": "%s (%s)" % (dom, kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_copy_gbs": copy_gbs,      # this box's device-to-device copy rate (read + write bytes), SURVEY 8(d)
-                         "avg_launch_ms": avg_ms, "launches_per_step": ex["launches"] / args.steps,
-                         "alg_bytes_per_launch": bytes_per_launch,
-                         "whole_path": {"alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9,
-                                        "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-            "kernels_ms_per_step": {k: v["ms"] for k, v in prof_all.items() if v["launches"]},      # from the untimed profiling step
-            "objective": int(obj),
-            "extras": {"ms_per_step_with_fixed_point_exit": fp_ms,
-                       "note": "same call with the exact early exit cp_set_option('fixed_point', 1) (off by default; never in `value`)"},
-        }
-        if not args.no_cpu_baseline:
-            a, samples = cpu_baseline(K, avg_deg)
-            t_full = a * K * float(n) * float(n)
-            out["cpu_baseline"] = {"value": 1.0 / t_full, "unit": "partitions/s", "cores": 1, "kind": "port",
-                                   "sample": "literal O(K n^2) restatement timed at n=%s (K=%d, same generator), "
-                                             "t = a*K*n^2 with a=%.3e s extrapolated to n=%d"
-                                             % ([s[0] for s in samples], K, a, n),
-                                   "sample_seconds": [s[1] for s in samples], "host_cores": os.cpu_count()}
+    if args.config == "2":
+        out = run_cfg2(args, dev) if rank == 0 else None
+    elif args.config == "4":
+        out = run_cfg4(args, dev) if rank == 0 else None
+    else:
+        res = run_dp(args, args.config, dev, rank, world, dist)
+        out = None
+        if res is not None:
+            out, B = res
+            if args.config == "3" and world == 1 and not args.no_extras:
+                # driver-visible lines of the other single-GPU configs: short runs on the same resident matrix
+                other = {}
+                sub = argparse.Namespace(**vars(args)); sub.steps = 2; sub.warmup = 1; sub.no_cpu_baseline = True
+                B.hip.csr_destroy(B.h); del B
+                torch.cuda.empty_cache()
+                for c in ("constrained", "bottleneck"):
+                    o, b2 = run_dp(sub, c, dev, 0, 1, None)
+                    other[c] = {"metric": o["metric"], "ms_per_step": o["ms_per_step"], "value": o["value"], "check": o["check"],
+                                "dominant_kernel": o["roofline"]["kernel"], "roofline_frac": o["roofline"]["frac"], "kernels_ms_per_step": o["kernels_ms_per_step"]}
+                    b2.hip.csr_destroy(b2.h); del b2
+                    torch.cuda.empty_cache()
+                sub.n = 0; sub.parts = 0
+                other["2"] = run_cfg2(sub, dev, brief=True)
+                out["extras"]["other_configs"] = other
+                if not args.no_cpu_baseline:
+                    nn, tc = cpu_convex_splitter(out["config"]["K"], out["config"]["nnz"] / out["config"]["n"], SEED + 2)
+                    out["extras"]["cpu_baseline_2"] = {"method": "ConvexTotalSplitter(AffineConnectivityModel(0,0,0,1)) (the reference's fastest exact-value method for this cost), oracle, 1 core",
+                                                       "n": nn, "K": out["config"]["K"], "seconds": tc,
+                                                       "note": "timed directly at n=%d (same generator); super-linear in n (wavelet queries leave cache): n=1e7 is out of reach" % nn}
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-    hip.csr_destroy(h)
     if dist is not None:
         dist.destroy_process_group()
 
