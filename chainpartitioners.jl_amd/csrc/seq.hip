@@ -320,6 +320,203 @@ __global__ void __launch_bounds__(64) k_pack_convex(SeqOracle<TC> O, SeqWeight W
     if (threadIdx.x == 0) *status = rc;
 }
 
+// ------------------------------------------------------------------ ConvexTotalChunker under a width window, LDS-resident
+// pack_stripe(A, ConvexTotalChunker(ConstrainedCost(f, VertexCount(), w)))  ConvexTotalChunker.jl:141-168, :211-265.
+// The stack algorithm is a dependent chain and its result on a cost that is not convex (the reference's own benchmark cost,
+// ColumnBlockComponentCostModel(3, w -> 1 + w), runbenchmarks.jl:21,33) is defined by nothing but its execution, so it is
+// executed -- but not out of HBM.  With the width weight the outer loop of chunk_convex_constrained! advances a window of w
+// columns per iteration and only ever touches columns [j0, j'1 + w] (:216-264): their costs (a ring of 64 columns), the rows of
+// the window table F[j'][j' - j] they need, the sigma re-indexing arrays and the candidate stack all live in LDS; the table
+// rows of the window after next are fetched into registers while the current window runs and enter the ring at its end, so
+// no step of the chain waits for HBM.  ptr leaves through plain stores.  Same statements, same order, same tie rules as
+// chunk_convex! / chunk_convex_constrained! above (which remain the general path: other weights, w > CW_MAXW).
+constexpr int CW_RING = 64;          // columns resident (>= 4 w + 2)
+constexpr int CW_MAXW = 15;
+constexpr int CW_FW = 2 * CW_MAXW + 3;      // table row: widths 0 .. 2 w + 2
+
+template <typename TC>
+struct CwState {
+    Ext<TC> cst[CW_RING];
+    TC F[CW_RING][CW_FW + 1];
+    int32_t sig_j[CW_RING], sig_jp[CW_RING], sig_ptr[CW_RING];
+    Ext<TC> sig_cst[CW_RING];
+    int32_t ftr[2 * CW_RING];
+};
+
+// scalars of the walk (registers); S is the kernel's __shared__ state, always passed by reference into force-inlined code so
+// that every access stays a DS instruction
+struct CwEnv {
+    int32_t n, Wc, lo_res, hi_res;       // rows of F / columns of cst resident: [lo_res, hi_res]
+    int32_t mode, I;                     // mode 1: sigma view -- indices are positions of the staircase problem
+};
+
+// the rare pair outside the resident table goes through the general oracle; kept out of line (its wavelet loops would sit in
+// the registers of the whole kernel)
+#ifdef CW_STATS
+__device__ unsigned long long g_cw_stats[8];
+#define CW_STAT(i) do { if (threadIdx.x == 0) g_cw_stats[i]++; } while (0)
+#else
+#define CW_STAT(i) do { } while (0)
+#endif
+template <typename TC>
+__device__ __noinline__ TC cw_ocl_general(const SeqOracle<TC> *O, int32_t j, int32_t jp) { CW_STAT(jp < j ? 0 : 1); return ocl(*O, (int64_t)j, (int64_t)jp, (int64_t)0); }
+
+// wave-uniform values read from LDS go to the scalar unit: the walk's index arithmetic and branches then cost SALU slots, not a
+// dependent VALU chain of the whole wave
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// f'(j, j') = cst[j] + f(j, j')  (:153-155).  Inside the walk every j lies in the current window and every j' in [j, j'1 + w], all
+// resident in the ring (k_pack_convex_win keeps [j0, j'1 + 3 w]); a pair with j > j' or j' - j > Wc -- possible only through
+// stale stack entries of a non-convex cost -- takes the general oracle
+template <typename TC>
+__device__ __forceinline__ Ext<TC> cw_base_eval(CwState<TC> &S, const CwEnv &E, const SeqOracle<TC> *O, int32_t j, int32_t jp)
+{
+    // both LDS reads are issued unconditionally (the table index clamped into the row), so that the reads of several evaluations
+    // of one step go out together; the rare pair outside the table replaces the value afterwards
+    const uint32_t d = (uint32_t)(jp - j);
+    const bool in_tab = d <= (uint32_t)E.Wc;
+    const Ext<TC> b = S.cst[j & (CW_RING - 1)];
+    TC fv = S.F[jp & (CW_RING - 1)][in_tab ? d : 0u];
+    if (!in_tab) fv = cw_ocl_general<TC>(O, j, jp);
+    Ext<TC> r; r.inf = b.inf; r.x = cadd(b.x, fv);
+    return r;
+}
+// the sigma view (:246): position a as a candidate is the real column sigma_j[I - a], position b as a target is sigma_j'[I - b]
+template <int MODE> __device__ __forceinline__ int32_t cw_xj(const int32_t *sig_j, const CwEnv &E, int32_t a) { return MODE ? uni(sig_j[E.I - a]) : a; }
+template <int MODE> __device__ __forceinline__ int32_t cw_xjp(const int32_t *sig_jp, const CwEnv &E, int32_t b) { return MODE ? uni(sig_jp[E.I - b]) : b; }
+template <typename TC, int MODE>
+__device__ __forceinline__ Ext<TC> cw_get(CwState<TC> &S, const CwEnv &E, int32_t jp)
+{
+    if (MODE) return S.sig_cst[jp];
+    return S.cst[jp & (CW_RING - 1)];
+}
+template <typename TC, int MODE>
+__device__ __forceinline__ void cw_set(CwState<TC> &S, const CwEnv &E, int64_t *__restrict__ ptr_g, int32_t jp, Ext<TC> c, int32_t p)
+{
+    if (MODE) { S.sig_cst[jp] = c; S.sig_ptr[jp] = p; return; }
+    S.cst[jp & (CW_RING - 1)] = c; ptr_g[jp] = p;
+}
+
+// chunk_convex!  ConvexTotalChunker.jl:57-112 on the LDS state (every j' visited lies in (j0, j'1]: inside the view, so the
+// WindowConstrainedMatrix range checks of the general path are vacuous here).  The top of the stack is mirrored in scalars
+// (tj, th): a step reads the stack only after a pop.
+template <typename TC, int MODE>
+__device__ __forceinline__ void cw_chunk_convex(CwState<TC> &S, const CwEnv &E, const SeqOracle<TC> *O, int64_t *__restrict__ ptr_g, int32_t j0, int32_t jp1)
+{
+    // (tj, th) mirror the top of the stack, rtj is the real column of tj: a step translates positions to columns once
+    int32_t top = 0, tj, th, rtj;
+#define CW_PUSH(a, ra, b) do { S.ftr[2 * top] = (a); S.ftr[2 * top + 1] = (b); top++; tj = (a); th = (b); rtj = (ra); } while (0)
+#define CW_POP() do { top--; if (top > 0) { tj = uni(S.ftr[2 * (top - 1)]); th = uni(S.ftr[2 * (top - 1) + 1]); rtj = cw_xj<MODE>(S.sig_j, E, tj); } } while (0)
+#define CW_F(rj, b) cw_base_eval<TC>(S, E, O, (rj), cw_xjp<MODE>(S.sig_jp, E, (b)))
+    CW_PUSH(j0, cw_xj<MODE>(S.sig_j, E, j0), jp1 + 1);
+    for (int32_t jp = j0 + 1; jp <= jp1; jp++) {
+        CW_STAT(2);
+        const int32_t rjm1 = cw_xj<MODE>(S.sig_j, E, jp - 1), rjp = cw_xjp<MODE>(S.sig_jp, E, jp);
+        const Ext<TC> c2 = cw_base_eval<TC>(S, E, O, rjm1, rjp);           // f(j' - 1, j')  (independent of the stack: issued first)
+        const Ext<TC> cur = cw_get<TC, MODE>(S, E, jp);
+        const int32_t j = tj, h = th;                                       // (j, h) = last(ftr)
+        const Ext<TC> c = cw_base_eval<TC>(S, E, O, rtj, rjp);             // f(j, j')
+        if (ext_le(c, c2)) {
+            if (ext_le(c, cur)) cw_set<TC, MODE>(S, E, ptr_g, jp, c, j);
+            if (h == jp + 1) CW_POP();
+        } else {
+            if (ext_le(c2, cur)) cw_set<TC, MODE>(S, E, ptr_g, jp, c2, jp - 1);
+            while (top > 0) {
+                CW_STAT(3);
+                const int32_t rh = cw_xjp<MODE>(S.sig_jp, E, th - 1);
+                if (ext_lt(cw_base_eval<TC>(S, E, O, rjm1, rh), cw_base_eval<TC>(S, E, O, rtj, rh))) CW_POP(); else break;
+            }
+            if (top == 0) {
+                CW_PUSH(jp - 1, rjm1, jp1 + 1);
+            } else {
+                int32_t hh = th, h_lo = jp + 1, h_hi = th - 1;
+                while (h_lo <= h_hi) {
+                    hh = (int32_t)(((uint32_t)(h_lo + h_hi)) >> 1);
+                    CW_STAT(4);
+                    const int32_t rh = cw_xjp<MODE>(S.sig_jp, E, hh - 1);
+                    if (ext_lt(cw_base_eval<TC>(S, E, O, rjm1, rh), cw_base_eval<TC>(S, E, O, rtj, rh))) h_lo = hh + 1; else h_hi = hh - 1;
+                }
+                hh = h_hi;
+                if (jp + 1 != hh) CW_PUSH(jp - 1, rjm1, hh);
+            }
+        }
+    }
+#undef CW_PUSH
+#undef CW_POP
+#undef CW_F
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int32_t w, int64_t *__restrict__ ptr, int32_t *__restrict__ status,
+                                                        const SeqOracle<TC> *__restrict__ Odev)
+{
+    __shared__ CwState<TC> S;
+    const int lane = threadIdx.x;
+    const int32_t n = (int32_t)Oarg.n, Jp1 = n + 1, Wc = (int32_t)Oarg.Wc, FWg = Wc + 1;
+    const TC *__restrict__ Ftab = Oarg.Ftab;
+    // ptr[] starts at zeros(Ti, n + 1) (:151): filled by the whole wave
+    for (int64_t t = lane; t <= (int64_t)n + 1; t += 64) ptr[t] = 0;
+    CwEnv E; E.n = n; E.Wc = Wc; E.mode = 0; E.I = 0;
+    for (int i = lane; i < CW_RING; i += 64) S.cst[i] = ext_inf<TC>();
+    __syncthreads();
+    // rows 1 .. hi of the table into the ring (row j' = F[j' * (Wc + 1) + d], d = j' - j)
+    int32_t hi_res = 1 + 4 * w;
+    if (hi_res > Jp1) hi_res = Jp1;
+    for (int32_t e = lane; e < hi_res * FWg; e += 64) {
+        const int32_t row = 1 + e / FWg, d = e - (row - 1) * FWg;
+        S.F[row & (CW_RING - 1)][d] = Ftab[(int64_t)row * FWg + d];
+    }
+    S.cst[1] = ext_of((TC)0);                                         // cst[1] = zero (:152)
+    __syncthreads();
+    E.lo_res = 1; E.hi_res = hi_res;
+    // chunk_convex_constrained!(cst, spl, f', w, w_max, 1, n + 1, ...)  (:211-265)
+    const int32_t J0 = 1;
+    int32_t jp1 = J0 + 1;
+    while (jp1 < Jp1 && (jp1 + 1 - J0) <= w) jp1 += 1;               // w(J0, j'1 + 1) <= w_max
+    int32_t j0 = J0;
+    int32_t rc = CP_OK;
+    if (n >= 1) for (;;) {
+        // the table rows of the columns that become visible after this iteration: (hi_res, min(n + 1, j'1 + 4 w)] -- into registers now,
+        // into the ring at the end
+        int32_t nx_hi = jp1 + 4 * w;
+        if (nx_hi > Jp1) nx_hi = Jp1;
+        const int32_t nx_cnt = nx_hi > E.hi_res ? (nx_hi - E.hi_res) * FWg : 0;
+        TC pre[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t e = lane + 64 * k;
+            pre[k] = (TC)0;
+            if (e < nx_cnt) { const int32_t ro = e / FWg, d = e - ro * FWg; pre[k] = Ftab[(int64_t)(E.hi_res + 1 + ro) * FWg + d]; }
+        }
+        cw_chunk_convex<TC, 0>(S, E, Odev, ptr, j0, jp1);
+        if (jp1 == Jp1) break;
+        int32_t jp = jp1, I = 1;
+        for (int32_t j = j0 + 1; j <= jp1; j++) {                     // (:224-238)
+            if (jp > jp1) { S.sig_jp[I] = jp; I += 1; S.sig_j[I] = j; }
+            while (jp < Jp1 && (jp + 1 - j) <= w) { jp += 1; S.sig_jp[I] = jp; I += 1; S.sig_j[I] = j; }
+        }
+        I += 1;
+        if (I == 2) { rc = CP_EINVAL; break; }
+        for (int32_t i = 2; i <= I - 1; i++) S.sig_cst[i] = ext_inf<TC>();
+        E.I = I;
+        cw_chunk_convex<TC, 1>(S, E, Odev, ptr, 1, I - 1);
+        for (int32_t ip = 2; ip <= I - 1; ip++) cw_set<TC, 0>(S, E, ptr, uni(S.sig_jp[I - ip]), S.sig_cst[ip], uni(S.sig_j[I - uni(S.sig_ptr[ip])]));
+        j0 = jp1;
+        jp1 = S.sig_jp[I - 2];
+        // the window moved: columns below the new j0 leave the ring, the prefetched rows enter it
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t e = lane + 64 * k;
+            if (e < nx_cnt) { const int32_t ro = e / FWg, d = e - ro * FWg, row = E.hi_res + 1 + ro; S.F[row & (CW_RING - 1)][d] = pre[k]; if (d == 0) S.cst[row & (CW_RING - 1)] = ext_inf<TC>(); }
+        }
+        __syncthreads();
+        if (nx_hi > E.hi_res) E.hi_res = nx_hi;
+        E.lo_res = j0;
+    }
+    if (lane == 0) *status = rc;
+}
+
 // ------------------------------------------------------------------ ConcaveTotalChunker.jl
 // chunk_concave!(cst, ptr, f, j0, j'1, ftr)  :57-114 ; ftr = CircularDeque of (j, h) pairs in dq[2*cap]
 template <typename TC>
@@ -744,7 +941,21 @@ int32_t run_pack_convex(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *
     CP_HIP(hipMemsetAsync(sig_ptr.p, 0, sig_ptr.bytes(), s));
     {
         ProfScope ps(PROF_CHUNK, s, 0.0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_convex<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, cst.p, ptr.p, ftr.p,
+        // width window with its table resident: the LDS form of the same algorithm (k_pack_convex_win)
+        const bool win = W.kind == CP_MODEL_VERTEX_COUNT && C->O.Ftab && wi >= 1 && wi <= CW_MAXW && C->O.Wc == 2 * wi + 2 && !g_opt_force_brute &&
+                         mdl->kind != CP_MODEL_BLOCK;
+        DBuf<SeqOracle<TC>> odev(1);                      // (the general oracle, for the rare pair outside the resident table)
+        if (win) {
+            CP_HIP(hipMemcpyAsync(odev.p, &C->O, sizeof(SeqOracle<TC>), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_convex_win<TC>), dim3(1), dim3(64), 0, s, C->O, (int32_t)wi, ptr.p, st.p, odev.p);
+            CP_HIP(hipStreamSynchronize(s));              // (odev leaves scope)
+#ifdef CW_STATS
+            unsigned long long st8[8];
+            CP_HIP(hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_cw_stats), sizeof(st8)));
+            fprintf(stderr, "cw stats: general(j>j')=%llu general(other)=%llu steps=%llu pops=%llu bsearch=%llu\n", st8[0], st8[1], st8[2], st8[3], st8[4]);
+#endif
+        }
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_convex<TC>), dim3(1), dim3(64), 0, s, C->O, W, constrained, cst.p, ptr.p, ftr.p,
                            sig_j.p, sig_jp.p, sig_ptr.p, sig_cst.p, st.p);
     }
     CP_HIP(hipGetLastError());
