@@ -22,7 +22,7 @@ SYMBOLS = [
     "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
-    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window",
+    "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window", "cp_dp_set_rows",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
     "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
 ]
@@ -292,6 +292,16 @@ class HipBackend:
         k = nb.value
         return k, opt.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), nn.reshape(-1)[:k * (n + 1)].reshape(k, n + 1), \
             (nl.reshape(-1)[:k * (n + 1)].reshape(k, n + 1) if hyper else None)
+
+    def dp_set_window(self, dp, wmax):
+        rc = self.lib.cp_dp_set_window(dp, _i64(wmax))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_set_window -> {rc}")
+
+    def dp_set_rows(self, dp, lo, hi):
+        rc = self.lib.cp_dp_set_rows(dp, _i64(lo), _i64(hi))
+        if rc != 0:
+            raise RuntimeError(f"cp_dp_set_rows({lo}, {hi}) -> {rc}")
 
     def windowed_layer(self, A, mm, W, wmax, lo=None, hi=None):
         """one DP layer over injected previous costs W (numpy, n+1) with the width window wmax: (cst[r], ptr[r]) 0-based,

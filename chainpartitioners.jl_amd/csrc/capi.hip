@@ -359,6 +359,7 @@ struct DpRun : DpBase {
     cp_csr_s *A = nullptr;
     int64_t K = 0, rlo = 0, rhi = 0;          // 0-based inclusive row window
     int64_t wwin = 0;                          // > 0: layers k >= 2 take their candidates from the width window max(0, r - wwin) <= p <= r (cp_dp_set_window)
+    std::vector<int64_t> lay_lo, lay_hi;       // the row tile every layer was computed with (cp_dp_set_rows moves it between layers)
     int32_t combine = 0, order = 0;
     cp_model_t mdl{};
     std::vector<TC> alpha_k_host;
@@ -382,6 +383,7 @@ static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, 
     int64_t n = A->n;
     D->A = A; D->K = K; D->combine = combine; D->order = order; D->mdl = *model;
     D->rlo = row_lo - 1; D->rhi = row_hi - 2;
+    D->lay_lo.assign((size_t)K + 1, 0); D->lay_hi.assign((size_t)K + 1, -1);      // (a layer this rank never computes owns no row)
     if (model->alpha_k && model->n_alpha_k > 0) {
         D->alpha_k_host.assign((const TC *)model->alpha_k, (const TC *)model->alpha_k + model->n_alpha_k);
         D->mdl.alpha_k = D->alpha_k_host.data();
@@ -428,6 +430,7 @@ static int32_t dp_layer(DpRun<TC> *D, int64_t k, const TC *prev, TC *cur)
     }
     CP_REQUIRE(prev && cur && k >= 2 && k <= D->K, CP_EINVAL, "bad layer");
     int64_t rlo = D->rlo < 0 ? 0 : D->rlo, rhi = D->rhi > n ? n : D->rhi;
+    D->lay_lo[(size_t)k] = rlo; D->lay_hi[(size_t)k] = rhi;
     if (rhi >= rlo) {
         CP_REQUIRE(D->wwin == 0 || D->fast, CP_EUNSUPPORTED, "the width window needs the O(n log^2 n) path");
         if (D->fast) dp_total_layer<TC>(A, D->HM.d, D->alpha_of(k), prev, cur, pk, D->work, rlo, rhi, D->wwin);
@@ -947,9 +950,10 @@ int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out)
         CP_REQUIRE(dp && out && k >= 1 && jp >= 1 && jp <= dp->A->n + 1, CP_EINVAL, "bad argument");
         CP_HIP(hipSetDevice(dp->A->device));
         int64_t rlo, rhi; DBuf<int32_t> *ptr; int64_t K;
-        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
-        else { auto *D = static_cast<DpRun<double> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
-        CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); ptr = &D->ptr; K = D->K; CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+                                   rlo = (size_t)k < D->lay_lo.size() ? D->lay_lo[(size_t)k] : D->rlo; rhi = (size_t)k < D->lay_hi.size() ? D->lay_hi[(size_t)k] : D->rhi; }
+        else { auto *D = static_cast<DpRun<double> *>(dp->impl); ptr = &D->ptr; K = D->K; CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+               rlo = (size_t)k < D->lay_lo.size() ? D->lay_lo[(size_t)k] : D->rlo; rhi = (size_t)k < D->lay_hi.size() ? D->lay_hi[(size_t)k] : D->rhi; }
         *out = 0;
         if (k == 1) { *out = 1; return CP_OK; }                 // ptr[:, 1] == 1 on every rank
         int64_t r = jp - 1;
@@ -960,6 +964,14 @@ int32_t cp_dp_ptr_at(cp_dp_t dp, int64_t k, int64_t jp, int64_t *out)
         *out = (int64_t)v + 1;
         return CP_OK;
     });
+}
+
+int32_t cp_dp_set_rows(cp_dp_t dp, int64_t row_lo, int64_t row_hi)
+{
+    if (!dp || row_lo < 1 || row_hi < row_lo || row_hi > dp->A->n + 2) return CP_EINVAL;
+    if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); D->rlo = row_lo - 1; D->rhi = row_hi - 2; }
+    else { auto *D = static_cast<DpRun<double> *>(dp->impl); D->rlo = row_lo - 1; D->rhi = row_hi - 2; }
+    return CP_OK;
 }
 
 int32_t cp_dp_set_window(cp_dp_t dp, int64_t wmax)
@@ -976,9 +988,10 @@ int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out)
         CP_REQUIRE(dp && out && k >= 1, CP_EINVAL, "bad argument");
         CP_HIP(hipSetDevice(dp->A->device));
         int64_t rlo, rhi; DBuf<int32_t> *ptr; int64_t K;
-        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
-        else { auto *D = static_cast<DpRun<double> *>(dp->impl); rlo = D->rlo; rhi = D->rhi; ptr = &D->ptr; K = D->K; }
-        CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+        if (dp->dtype == CP_I64) { auto *D = static_cast<DpRun<int64_t> *>(dp->impl); ptr = &D->ptr; K = D->K; CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+                                   rlo = (size_t)k < D->lay_lo.size() ? D->lay_lo[(size_t)k] : D->rlo; rhi = (size_t)k < D->lay_hi.size() ? D->lay_hi[(size_t)k] : D->rhi; }
+        else { auto *D = static_cast<DpRun<double> *>(dp->impl); ptr = &D->ptr; K = D->K; CP_REQUIRE(k <= K, CP_EINVAL, "bad layer");
+               rlo = (size_t)k < D->lay_lo.size() ? D->lay_lo[(size_t)k] : D->rlo; rhi = (size_t)k < D->lay_hi.size() ? D->lay_hi[(size_t)k] : D->rhi; }
         const int64_t n = dp->A->n;
         if (k == 1) { for (int64_t r = 0; r <= n; r++) out[r] = 1; return CP_OK; }
         std::vector<int32_t> h((size_t)n + 1);

@@ -170,7 +170,7 @@ static BnWork *bn_work_get(cp_csr_s *A)
     return reinterpret_cast<BnWork *>(A->bn_work);
 }
 
-int64_t g_opt_bn_chunk = 128;
+int64_t g_opt_bn_chunk = 8;       // (config 3 matrix, K = 64: 8 rows 0.50 s, 32 rows 0.58 s, 128 rows 0.97 s, 256 rows 1.32 s per partition)
 
 template <typename TC>
 void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,

@@ -176,6 +176,9 @@ int32_t cp_dp_ptr_row(cp_dp_t dp, int64_t k, int64_t *out /* n+1 */);
  * range of the ConstrainedCost splitter with a VertexCount weight, DynamicSplitter.jl:233-246); 0 restores the full range.
  * The layer windows j'_lo / j'_hi are the caller's business (the row tile, and a huge cost outside the previous window). */
 int32_t cp_dp_set_window(cp_dp_t dp, int64_t wmax);
+/* moves this rank's row tile [row_lo, row_hi) for the layers computed from now on (the constrained DP tiles every layer's own
+ * window j'_lo[k] .. j'_hi[k] over the ranks); cp_dp_ptr_at / cp_dp_ptr_row answer with the tile each layer was computed with */
+int32_t cp_dp_set_rows(cp_dp_t dp, int64_t row_lo, int64_t row_hi);
 int32_t cp_dp_block_tables(cp_dp_t dp, int32_t *nplanes_out, int64_t *opt_out, int64_t *nets_out, int64_t *selfnets_out);
 int32_t cp_dp_destroy(cp_dp_t dp);
 

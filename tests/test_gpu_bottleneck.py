@@ -53,7 +53,7 @@ def test_chunk_sizes_and_general_sweep_agree(hip, orc):
             try:
                 rc1, p1, c1 = hip.dynamic_tables(A, K, 1, mm, None)
             finally:
-                hip.set_option("bn_chunk", 128)
+                hip.set_option("bn_chunk", 8)
             assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ch
         hip.set_option("force_brute", 1)
         try:

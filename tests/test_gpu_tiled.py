@@ -1,6 +1,8 @@
-"""Row-tiled DP (the multi-GPU path, chainpartitioners.jl_amd/distributed.py) on ONE GPU: G ranks are simulated in
-one process -- every rank computes only its tile of each layer into the shared layer buffer, exactly the data flow the
-RCCL all_gather implements -- and the split vector must equal the single-rank result and the CPU oracle."""
+"""Row-tiled DP (the multi-GPU path, chainpartitioners.jl_amd/distributed.py) on ONE GPU: G ranks are simulated in one
+process -- every rank computes only its tile of each layer into the shared layer buffer, exactly the data flow the RCCL
+all_gather implements.  Compared with the oracle at TABLE level: every rank's slice of ptr[:, k] and the gathered cst[:, k] of
+every layer -- for the total-cost DP (whose split vector is the closed form [1, n+1, ...] and says nothing), the bottleneck DP
+and the width-constrained DP (non-trivial split vectors) -- then two real processes over gloo."""
 import numpy as np
 import pytest
 import torch
@@ -11,51 +13,93 @@ pytestmark = pytest.mark.gpu
 
 
 def run_simulated(hip, A, K, method, world):
+    """-> (spl, cst[j', k] as gathered, ptr[j', k] merged from the ranks' slices)"""
     from chainpartitioners_jl_amd.distributed import TiledDP
     dev = torch.device("cuda", 0)
     h = hip.csr(A)
-    ranks = [TiledDP(hip, h, A.n, K, method, g, world, dev) for g in range(world)]
+    n = A.n
+    ranks = [TiledDP(hip, h, n, K, method, g, world, dev) for g in range(world)]
     try:
-        shared_prev = ranks[0].prev
-        shared_cur = ranks[0].cur
+        if not ranks[0].feasible:
+            spl = np.ones(K + 1, dtype=np.int64); spl[K] = n + 1
+            return spl, None, None
+        shared_prev, shared_cur = ranks[0].prev, ranks[0].cur
         for T in ranks:                                   # all ranks share the two layer buffers (= the gathered vectors)
             T.prev, T.cur = shared_prev, shared_cur
+        cst = np.zeros((n + 1, K), dtype=np.int64 if ranks[0].dtype == torch.int64 else np.float64)
+        ptr = np.zeros((n + 1, K), dtype=np.int64)
         ranks[0].step_layer(1)
+        for T in ranks:
+            T.complete_layer(1)
+        cst[:, 0] = ranks[0].cur[:n + 1].cpu().numpy(); ptr[:, 0] = 1
         for T in ranks:
             T.swap()
         for k in range(2, K + 1):
             for T in ranks:
+                T.begin_layer(k)
                 T.step_layer(k)                           # writes only its own tile of `cur`
+            for T in ranks:
+                T.complete_layer(k)
+            cst[:, k - 1] = ranks[0].cur[:n + 1].cpu().numpy()
+            for T in ranks:
+                ptr[:, k - 1] = np.maximum(ptr[:, k - 1], hip.dp_ptr_row(T.dp, k, n))
             for T in ranks:
                 T.swap()
         spl = np.zeros(K + 1, dtype=np.int64)
-        spl[K] = A.n + 1
+        spl[K] = n + 1
         for k in range(K, 0, -1):
             spl[k - 1] = max(T.ptr_at(k, int(spl[k])) for T in ranks)       # the MAX all_reduce
-        return spl
+        return spl, cst, ptr
     finally:
         for T in ranks:
             T.close()
 
 
-def test_tiled_equals_single_rank_and_oracle(hip, orc):
+def mats():
     rng = np.random.default_rng(77)
-    mats = [sprand(8, 16, 0.3, rng), sprand(20, 40, 0.1, rng), sprand(9, 65, 0.2, rng), golden_matrices()["HB/can_292"],
+    return [sprand(8, 16, 0.3, rng), sprand(20, 40, 0.1, rng), sprand(9, 65, 0.2, rng), golden_matrices()["HB/can_292"],
             golden_matrices()["LPnetlib/lp_etamacro"], suitesparse_shaped(3000, 6, 5)]
-    for A in mats:
+
+
+def test_tiled_tables_equal_the_oracle(hip, orc):
+    for A in mats():
+        n = A.n
         for K in (2, 3, 5):
-            for mdl in (cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineConnectivityModel(0, 0, 0, 1),
-                        cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=list(range(1, K + 1)))):
-                meth = cp.DynamicTotalSplitter(mdl)
+            for mdl, g in ((cp.AffineConnectivityModel(0, 10, 1, 100), 0), (cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1), 0),
+                           (cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=list(range(1, K + 1))), 0),
+                           (cp.AffineConnectivityModel(0, 10, 1, 100), 1), (cp.AffineWorkModel(0, 10, 1), 1)):
+                meth = (cp.DynamicBottleneckSplitter if g else cp.DynamicTotalSplitter)(mdl)
+                rc, optr, ocst = orc.dynamic_tables(A, K, g, mdl.marshal(), None)
                 want = cp.partition_stripe(A, K, meth, backend=orc).spl
                 for world in (1, 2, 3, 8):
-                    got = run_simulated(hip, A, K, meth, world)
-                    assert np.array_equal(got, want), (A, K, mdl.kind, world)
-            # bottleneck objective: general sweep, tiled the same way
-            meth = cp.DynamicBottleneckSplitter(cp.AffineConnectivityModel(0, 3, 1, 3))
-            if A.n <= 1000:
-                want = cp.partition_stripe(A, K, meth, backend=orc).spl
-                assert np.array_equal(run_simulated(hip, A, K, meth, 3), want)
+                    spl, cst, ptr = run_simulated(hip, A, K, meth, world)
+                    assert np.array_equal(spl, want), (A, K, mdl.kind, g, world)
+                    # layers 1 .. K-1 are complete in the reference tables; layer K holds row n+1 only
+                    assert np.array_equal(cst[:, :K - 1], ocst[:, :K - 1]) and np.array_equal(ptr[:, :K - 1], optr[:, :K - 1]), (A, K, g, world)
+                    assert cst[n, K - 1] == ocst[n, K - 1] and ptr[n, K - 1] == optr[n, K - 1]
+
+
+def test_tiled_constrained_tables_equal_the_oracle(hip, orc):
+    """the width-constrained DP: every layer's window is tiled over the ranks afresh; non-degenerate split vectors"""
+    nondeg = 0
+    for A in mats():
+        n = A.n
+        for K in (2, 3, 5, 8):
+            for w in sorted({max(1, -(-n // K)), max(1, -(-3 * n // (2 * K))), max(1, n // 2)}):
+                for mdl in (cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3)):
+                    meth = cp.DynamicTotalSplitter(cp.ConstrainedCost(mdl, cp.VertexCount(), w))
+                    rc, lo, hi, optr, ocst = orc.dynamic_tables_constrained(A, K, 0, mdl.marshal(), None, cp.VertexCount().marshal(), w, float(w))
+                    want = cp.partition_stripe(A, K, meth, backend=orc).spl
+                    for world in (1, 2, 3, 8):
+                        spl, cst, ptr = run_simulated(hip, A, K, meth, world)
+                        assert np.array_equal(spl, want), (A, K, w, world)
+                        if rc == 0:
+                            for k in range(1, K + 1):
+                                a, b = lo[k - 1] - 1, hi[k - 1]
+                                assert np.array_equal(cst[a:b, k - 1], ocst[a:b, k - 1]), (A, K, w, world, k)
+                                assert np.array_equal(ptr[a:b, k - 1], optr[a:b, k - 1]), (A, K, w, world, k)
+                    nondeg += int(len(set(want.tolist())) > 2)
+    assert nondeg > 20
 
 
 def _tiled_worker(rank, world, port, q):
@@ -73,17 +117,21 @@ def _tiled_worker(rank, world, port, q):
     hipb = _lib.HipBackend(0)
     A = ss(4000, 6, 11)
     K = 6
-    meth = cpm.DynamicTotalSplitter(cpm.AffineConnectivityModel(0, 10, 1, 100))
-    spl = partition_stripe_tiled(hipb, hipb.csr(A), A.n, K, meth, device=torch.device("cuda", 0))
+    net = cpm.AffineConnectivityModel(0, 10, 1, 100)
+    out = []
+    for meth in (cpm.DynamicTotalSplitter(net), cpm.DynamicBottleneckSplitter(net),
+                 cpm.DynamicTotalSplitter(cpm.ConstrainedCost(net, cpm.VertexCount(), 1000))):
+        spl = partition_stripe_tiled(hipb, hipb.csr(A), A.n, K, meth, device=torch.device("cuda", 0))
+        out.append(spl.tolist())
     if rank == 0:
-        q.put(spl.tolist())
+        q.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_tiled_two_processes_gloo(hip, orc):
     """Two real processes (both on this box's single GPU; collectives rehearsed over gloo, as RCCL needs one GPU
-    per rank): same driver code path as bench.py --mode tiled."""
+    per rank): same driver code path as bench.py --mode tiled -- total, bottleneck and constrained methods."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -97,5 +145,9 @@ def test_tiled_two_processes_gloo(hip, orc):
         p.join(timeout=120)
         assert p.exitcode == 0
     A = suitesparse_shaped(4000, 6, 11)
-    want = cp.partition_stripe(A, 6, cp.DynamicTotalSplitter(cp.AffineConnectivityModel(0, 10, 1, 100)), backend=orc).spl
-    assert got == want.tolist()
+    net = cp.AffineConnectivityModel(0, 10, 1, 100)
+    want = [cp.partition_stripe(A, 6, m, backend=orc).spl.tolist()
+            for m in (cp.DynamicTotalSplitter(net), cp.DynamicBottleneckSplitter(net),
+                      cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
+    assert got == want
+    assert len(set(want[1])) > 2 and len(set(want[2])) > 2          # the last two are informative
