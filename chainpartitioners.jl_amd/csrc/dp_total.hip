@@ -2531,7 +2531,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
         // (the shape is recorded only after every allocation succeeded: a hipMalloc failure leaves n == -1 and the next call starts over)
-        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false;
+        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.win_built = false;      // (the window anchors of a hyperedge model carry a second array)
         Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
