@@ -20,4 +20,4 @@ from .models import (PowerWorkModel, ConvexWorkModel, ConcaveWorkModel,   # noqa
 from . import _lib  # noqa: F401
 from .api import (adjointpattern, partition_plaid, partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
                   bottleneck_value, netcount, selfnetcount, dominancecount, set_default_backend,
-                  get_backend, CPError)
+                  get_backend, CPError, Step, Same, Next, Prev, Jump)

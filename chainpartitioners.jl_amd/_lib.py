@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("CP_LIB_PATH") or os.path.join(_HERE, "libchainpart.so
 SYMBOLS = [
     "cp_last_error", "cp_version", "cp_device_count", "cp_csr_create", "cp_csr_create_device", "cp_csr_destroy",
     "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise",
-    "cp_oracle_eval", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
+    "cp_oracle_eval", "cp_oracle_step", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window", "cp_dp_set_rows",
@@ -179,6 +179,12 @@ class HipBackend:
         of = out if out.dtype == np.float64 else None
         return self.lib.cp_oracle_eval(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None, C.c_int32(hint),
                                        _i64(j.size), _p(j), _p(jp), _p(k), _p(oi), _p(of))
+
+    def oracle_step(self, A, mm, rp, mj, j, mjp, jp, k, out):
+        oi = out if out.dtype == np.int64 else None
+        of = out if out.dtype == np.float64 else None
+        return self.lib.cp_oracle_step(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None, _i64(j.size),
+                                       _p(mj), _p(j), _p(mjp), _p(jp), _p(k), _p(oi), _p(of))
 
     def bound_stripe(self, A, K, mm):
         li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

@@ -220,6 +220,59 @@ class Oracle:
         return out[0].item() if scalar else out
 
 
+class _Move:
+    code = None
+
+    def __init__(self, arg):
+        self.arg = int(arg)
+
+
+class Same(_Move):
+    code = 0
+
+
+class Next(_Move):
+    code = 1
+
+
+class Prev(_Move):
+    code = 2
+
+
+class Jump(_Move):
+    code = 3
+
+
+class Step:
+    """Step(ocl)(Same(j) | Next(j) | Prev(j) | Jump(j), <same for j'>, [Same(k)])  (Costs.jl:174-195).  Single calls keep the
+    walk's previous position (the moves are promises about it, checked by the backend); `walk` takes a whole sequence."""
+
+    def __init__(self, ocl):
+        self.ocl = ocl
+        self._last = None
+
+    def __call__(self, mj, mjp, mk=None):
+        k = None if mk is None else (mk.arg if isinstance(mk, _Move) else int(mk))
+        if self._last is None:
+            vals = self.walk([(mj, mjp, k)])
+        else:                                       # replay the previous position so that the promise is checked
+            vals = self.walk([(Jump(self._last[0]), Jump(self._last[1]), self._last[2]), (mj, mjp, k)])
+        self._last = (mj.arg, mjp.arg, k)
+        return vals[-1].item()
+
+    def walk(self, moves):
+        o = self.ocl
+        mj = np.array([m[0].code for m in moves], dtype=np.int32); j = np.array([m[0].arg for m in moves], dtype=np.int64)
+        mjp = np.array([m[1].code for m in moves], dtype=np.int32); jp = np.array([m[1].arg for m in moves], dtype=np.int64)
+        ks = [m[2] if len(m) > 2 else None for m in moves]
+        kk = None if all(x is None for x in ks) else np.array([0 if x is None else (x.arg if isinstance(x, _Move) else int(x)) for x in ks], dtype=np.int64)
+        _, mm, _, _, _, rp, keep = _marshal(o.A, o.mdl, o.Pi)
+        out = np.zeros(j.shape, dtype=o.mdl.cost_dtype())
+        rc = o.backend.oracle_step(o.A, mm, rp, mj, j, mjp, jp, kk, out)
+        _check(rc, "Step(oracle)", o.backend)
+        return out
+
+
 def oracle_stripe(hint, mdl, A, Pi=None, *, backend=None) -> Oracle:
     return Oracle(hint, mdl, A, Pi, get_backend(backend))
 

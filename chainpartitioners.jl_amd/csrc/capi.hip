@@ -730,6 +730,23 @@ int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *
     });
 }
 
+int32_t cp_oracle_step(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, int64_t nq, const int32_t *move_j, const int64_t *j,
+                       const int32_t *move_jp, const int64_t *jp, const int64_t *k, int64_t *out_i64, double *out_f64)
+{
+    if (nq > 0 && (!move_j || !move_jp || !j || !jp)) { set_error("null argument"); return CP_EINVAL; }
+    for (int64_t t = 0; t < nq; t++) {
+        for (int side = 0; side < 2; side++) {
+            const int32_t mv = side ? move_jp[t] : move_j[t];
+            const int64_t *x = side ? jp : j;
+            if (mv < CP_MOVE_SAME || mv > CP_MOVE_JUMP) { set_error("Step: unknown move code"); return CP_EINVAL; }
+            if (t == 0 || mv == CP_MOVE_JUMP) continue;
+            const int64_t want = mv == CP_MOVE_SAME ? x[t - 1] : mv == CP_MOVE_NEXT ? x[t - 1] + 1 : x[t - 1] - 1;
+            if (x[t] != want) { set_error("Step: a Same / Next / Prev move does not match the previous position"); return CP_EINVAL; }
+        }
+    }
+    return cp_oracle_eval(A, model, Pi, CP_HINT_STEP, nq, j, jp, k, out_i64, out_f64);
+}
+
 int32_t cp_objective(cp_csr_t A, int64_t K, const int64_t *spl, const cp_model_t *model, const cp_rowpart_t *Pi,
                      int32_t combine, int64_t *out_i64, double *out_f64)
 {

@@ -76,6 +76,15 @@ int32_t cp_partwise(cp_csr_t csr, int64_t K, const int64_t *asg, int64_t *nprime
 int32_t cp_oracle_eval(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint,
                        int64_t nq, const int64_t *j, const int64_t *jp, const int64_t *k,
                        int64_t *out_i64, double *out_f64);
+/* Step(ocl)(move_j(j), move_j'(j'), Same(k)) along a walk of nq calls (Costs.jl:174-195; the specialised methods
+ * ConnectivityCosts.jl:66-76, HyperedgeCutCosts.jl:53-64, SparseColorArrays.jl:127-152, 231-256): move codes CP_MOVE_*.
+ * A move is the caller's promise about the previous call's position (Same: equal, Next: +1, Prev: -1, Jump: anything); the
+ * reference's stepwise structures rely on it, the device counters are random-access and do not -- so the promise is CHECKED
+ * (CP_EINVAL on a broken one; the first call may carry any move) and the value is ocl(j, j', k), which is what every Step
+ * method of the reference returns (Costs.jl:195). */
+int32_t cp_oracle_step(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi, int64_t nq,
+                       const int32_t *move_j, const int64_t *j, const int32_t *move_jp, const int64_t *jp,
+                       const int64_t *k, int64_t *out_i64, double *out_f64);
 /* bound_stripe(A, K, mdl)  WorkCosts.jl:37-51, ConnectivityCosts.jl:22-35 */
 int32_t cp_bound_stripe(cp_csr_t csr, int64_t K, const cp_model_t *model,
                         int64_t *lo_i64, int64_t *hi_i64, double *lo_f64, double *hi_f64);

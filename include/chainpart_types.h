@@ -118,6 +118,12 @@ typedef struct cp_rowpart {
 #define CP_HINT_SPARSE 2   /* DominanceCount (radix tree) */
 #define CP_HINT_STEP   3   /* SparseStepwiseDominanceCount */
 
+/* moves of the Step protocol: Step(ocl)(Same(j) | Next(j) | Prev(j) | Jump(j), ...)  (Costs.jl:174-195) */
+#define CP_MOVE_SAME 0
+#define CP_MOVE_NEXT 1
+#define CP_MOVE_PREV 2
+#define CP_MOVE_JUMP 3
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,12 @@ int32_t orc_oracle_eval(int64_t m, int64_t n, int64_t N, const int64_t *pos, con
                         int64_t nq, const int64_t *j, const int64_t *jp, const int64_t *k,
                         int64_t *out_i64, double *out_f64);
 
+/* Step(ocl)(move_j(j), move_j'(j'), Same(k)) along a walk (Costs.jl:174-195; moves CP_MOVE_SAME / NEXT / PREV / JUMP):
+ * the StepHint oracle of the reference is stepped in the given order */
+int32_t orc_oracle_step(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                        const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int32_t *move_j, const int64_t *j,
+                        const int32_t *move_jp, const int64_t *jp, const int64_t *k, int64_t *out_i64, double *out_f64);
+
 /* bound_stripe(A, K, mdl) WorkCosts.jl:37-51, ConnectivityCosts.jl:22-35 */
 int32_t orc_bound_stripe(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
                          int64_t K, const cp_model_t *mdl,

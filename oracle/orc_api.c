@@ -10,6 +10,9 @@
     int32_t orc_api_oracle_eval##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,            \
                                    const cp_model_t *, const cp_rowpart_t *, int32_t, int64_t,             \
                                    const int64_t *, const int64_t *, const int64_t *, T *);                \
+    int32_t orc_api_oracle_step##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *,            \
+                                   const cp_model_t *, const cp_rowpart_t *, int64_t, const int32_t *,     \
+                                   const int64_t *, const int32_t *, const int64_t *, const int64_t *, T *); \
     int32_t orc_api_bound_stripe##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t,  \
                                     const cp_model_t *, T *, T *);                                         \
     int32_t orc_api_bound_stripe_pi##S(int64_t, int64_t, int64_t, const int64_t *, const int64_t *, int64_t,   \
@@ -111,6 +114,14 @@ int32_t orc_dynamic_tables(int64_t m, int64_t n, int64_t N, const int64_t *pos, 
 {
     return IS_I(mdl) ? orc_api_dynamic_tables_i64(m, n, N, pos, idx, K, combine, mdl, Pi, ptr_out, cst_i64)
                      : orc_api_dynamic_tables_f64(m, n, N, pos, idx, K, combine, mdl, Pi, ptr_out, cst_f64);
+}
+
+int32_t orc_oracle_step(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,
+                        const cp_model_t *mdl, const cp_rowpart_t *Pi, int64_t nq, const int32_t *move_j, const int64_t *j,
+                        const int32_t *move_jp, const int64_t *jp, const int64_t *k, int64_t *out_i64, double *out_f64)
+{
+    return IS_I(mdl) ? orc_api_oracle_step_i64(m, n, N, pos, idx, mdl, Pi, nq, move_j, j, move_jp, jp, k, out_i64)
+                     : orc_api_oracle_step_f64(m, n, N, pos, idx, mdl, Pi, nq, move_j, j, move_jp, jp, k, out_f64);
 }
 
 int32_t orc_dynamic_tables_constrained(int64_t m, int64_t n, int64_t N, const int64_t *pos, const int64_t *idx,

@@ -113,6 +113,12 @@ class OracleBackend:
         return lib().orc_oracle_eval(*self._A(A), mm.ptr, C.byref(rp) if rp is not None else None, C.c_int32(hint),
                                      _i64(j.size), _p(j), _p(jp), _p(k), _p(oi), _p(of))
 
+    def oracle_step(self, A, mm, rp, mj, j, mjp, jp, k, out):
+        oi = out if out.dtype == np.int64 else None
+        of = out if out.dtype == np.float64 else None
+        return lib().orc_oracle_step(*self._A(A), mm.ptr, C.byref(rp) if rp is not None else None, _i64(j.size),
+                                     _p(mj), _p(j), _p(mjp), _p(jp), _p(k), _p(oi), _p(of))
+
     def bound_stripe(self, A, K, mm):
         li, hi, lf, hf = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         rc = lib().orc_bound_stripe(*self._A(A), _i64(K), mm.ptr, C.byref(li), C.byref(hi), C.byref(lf), C.byref(hf))

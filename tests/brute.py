@@ -60,6 +60,9 @@ def cost_table(A, mdl, k=None, NT=None, ST=None):
     nv = (R - P).astype(np.int64)
     npins = (pos[R] - pos[P]).astype(np.int64)
     dt = np.int64 if mdl.dtype == cp.models.CP_I64 else np.float64
+    if mdl.kind == cp.models.CP_MODEL_POWER_WORK:              # alpha + (nv*b_vertex + np*b_pin)^gamma  (test_Partitioners.jl:54-74)
+        x = nv.astype(np.float64) * mdl.beta_vertex + npins.astype(np.float64) * mdl.beta_pin
+        return np.triu(mdl.alpha + (x * x if mdl.gamma == 2.0 else np.power(np.maximum(x, 0.0), mdl.gamma)))
     a = mdl.alpha if (getattr(mdl, "alpha_k", None) is None or k is None) else mdl.alpha_k[k - 1]
     F = np.full((n + 1, n + 1), a, dtype=dt)
     F = F + nv.astype(dt) * dt(mdl.beta_vertex)
@@ -110,3 +113,35 @@ def block_argmins(W, F, nbits):
             v = W[rb - (1 << b):rb] + F[rb - (1 << b):rb, r]
             opt[b, r] = rb - (1 << b) + _rightmost_argmin(v)
     return opt
+
+
+def lws_optimum(F, wmax=None):
+    """min total cost of covering 0 .. n with parts [p, r) of width <= wmax (any number of parts): the least-weight
+    subsequence problem of pack_stripe(A, *TotalChunker(f))"""
+    n1 = F.shape[0]
+    best = np.full(n1, np.inf); best[0] = 0.0
+    for r in range(1, n1):
+        a = 0 if wmax is None else max(0, r - wmax)
+        best[r] = np.min(best[a:r] + F[a:r, r])
+    return best[n1 - 1]
+
+
+def kpart_optimum(Fk, K, wmax=None):
+    """min total cost of K consecutive (possibly empty) parts, part k costed by Fk(k) (1-based), widths <= wmax"""
+    n1 = Fk(1).shape[0]
+    cst = Fk(1)[0, :].astype(np.float64).copy()
+    if wmax is not None:
+        cst[wmax + 1:] = np.inf
+    for k in range(2, K + 1):
+        F = Fk(k)
+        new = np.full(n1, np.inf)
+        for r in range(n1):
+            a = 0 if wmax is None else max(0, r - wmax)
+            new[r] = np.min(cst[a:r + 1] + F[a:r + 1, r])
+        cst = new
+    return cst[n1 - 1]
+
+
+def partition_value(F_of_k, spl):
+    """total cost of a split vector (1-based) from the definition tables"""
+    return sum(F_of_k(k + 1)[spl[k] - 1, spl[k + 1] - 1] for k in range(len(spl) - 1))
