@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CP_LIB_PATH") or os.path.join(_HERE, "libchainpart.so
 
 SYMBOLS = [
     "cp_last_error", "cp_version", "cp_device_count", "cp_csr_create", "cp_csr_create_device", "cp_csr_destroy",
-    "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise",
+    "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise", "cp_domsum_build", "cp_rook_build", "cp_wsum_query", "cp_wsum_destroy",
     "cp_oracle_eval", "cp_oracle_step", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
@@ -238,6 +238,40 @@ class HipBackend:
 
     def count_free(self, kind, h):
         self.lib.cp_count_destroy(h)
+
+    # ---- weighted dominance (a13)
+    def domsum_build(self, A, val):
+        val = np.ascontiguousarray(val)
+        dt = M.CP_F64 if val.dtype == np.float64 else M.CP_I64
+        h = C.c_void_p()
+        rc = self.lib.cp_domsum_build(self._h(A), C.c_int32(dt), _p(val), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cp_domsum_build -> {rc}: {self.last_error()}")
+        return h, dt
+
+    def rook_build(self, N, idx, val=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        dt = M.CP_I64
+        if val is not None:
+            val = np.ascontiguousarray(val)
+            dt = M.CP_F64 if val.dtype == np.float64 else M.CP_I64
+        h = C.c_void_p()
+        rc = self.lib.cp_rook_build(_i64(N), _p(idx), C.c_int32(dt), _p(val), C.c_int32(self.device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cp_rook_build -> {rc}: {self.last_error()}")
+        return h, dt
+
+    def wsum_query(self, h, dt, i, j, unsigned=False):
+        i = np.ascontiguousarray(i, dtype=np.int64); j = np.ascontiguousarray(j, dtype=np.int64)
+        cnt = np.zeros(i.shape, dtype=np.int64)
+        sm = np.zeros(i.shape, dtype=np.float64 if dt == M.CP_F64 else (np.uint64 if unsigned else np.int64))
+        rc = self.lib.cp_wsum_query(h, _i64(i.size), _p(i), _p(j), _p(cnt), _p(sm) if dt == M.CP_I64 else None, _p(sm) if dt == M.CP_F64 else None)
+        if rc != 0:
+            raise RuntimeError(f"cp_wsum_query -> {rc}: {self.last_error()}")
+        return cnt, sm
+
+    def wsum_free(self, h):
+        self.lib.cp_wsum_destroy(h)
 
     def link_array(self, A):
         out = np.zeros(max(A.nnz, 1), dtype=np.int64)

@@ -65,6 +65,19 @@ int32_t cp_count_destroy(cp_count_t h);
 /* the NetCount link array idx'[q] = (n+1) - hst[i] (SparseColorArrays.jl:106-113), for tests */
 int32_t cp_link_array(cp_csr_t csr, int64_t *out /* N */);
 
+/* ---- weighted dominance (used by no cost oracle of the path, kept for the reference's AbstractMatrix API) ----
+ * dominancesum(hint, A)                 SparsePrefixMatrices.jl:1-250   S[i, j] = sum(A[1:i-1, 1:j-1])  (test_SparsePrefixMatrices.jl:15)
+ * rookcount!(hint, N, idx) / rooksum!(hint, N, idx, val)  :825-1273   the same over ONE point (idx[j], j) per column
+ * val: nnz (rook: N) 8-byte weights in the pattern's entry order -- CP_I64: Int / UInt words, summed with wrap-around exactly as
+ * Julia does; CP_F64: Float64 (a prefix-sum structure like the reference's `scn`: equal up to rounding, not bit for bit).
+ * One query returns the count (rows < i among the entries of the columns < j) and the weighted sum. */
+typedef struct cp_wsum_s *cp_wsum_t;
+int32_t cp_domsum_build(cp_csr_t csr, int32_t dtype, const void *val, cp_wsum_t *out);
+int32_t cp_rook_build(int64_t N, const int64_t *idx, int32_t dtype, const void *val /* NULL: counts only */, int32_t device, cp_wsum_t *out);
+int32_t cp_wsum_query(cp_wsum_t h, int64_t nq, const int64_t *i, const int64_t *j, int64_t *count_out /* may be NULL */,
+                      int64_t *sum_i64, double *sum_f64);
+int32_t cp_wsum_destroy(cp_wsum_t h);
+
 /* partwise(A, Pi) PartwiseCounts.jl:1-60 */
 int32_t cp_partwise(cp_csr_t csr, int64_t K, const int64_t *asg, int64_t *nprime_out,
                     int64_t *pios_out /* K+1 */, int64_t *prm_out /* <= N */,

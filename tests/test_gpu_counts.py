@@ -63,3 +63,56 @@ def test_partwise_matches_oracle(hip, orc):
         assert got[0] == want[0]
         for a, b in zip(got[1:], want[1:]):
             assert np.array_equal(a, b)
+
+
+def test_dominancesum_and_rooks_match_their_definition(hip):
+    """a13: dominancesum / rookcount! / rooksum! (SparsePrefixMatrices.jl:1-250, 825-1273) against the reference test's own
+    definitions, ref_dominancesum(A, i, j) = sum(A[1:i-1, 1:j-1]) with UInt weights and wrap-around sums
+    (test_SparsePrefixMatrices.jl:15, 41-71), on the reference's dimensions"""
+    rng = np.random.default_rng(0xDEADBEEF)
+    dims = list(range(1, 17)) + [31, 32, 33, 63, 64, 65]
+    for m in dims:
+        for n in (1, 2, 3, 7, 8, 9, 33):
+            A = sprand(m, n, 0.5, rng)
+            val = rng.integers(0, 2 ** 63, A.nnz, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, A.nnz).astype(np.uint64)
+            D = np.zeros((m, n), dtype=np.uint64)
+            cols = np.repeat(np.arange(n), np.diff(A.colptr))
+            D[A.rowval - 1, cols] = val
+            P = np.zeros((m + 1, n + 1), dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                P[1:, 1:] = np.cumsum(np.cumsum(D, axis=0, dtype=np.uint64), axis=1, dtype=np.uint64)
+            h, dt = hip.domsum_build(A, val)
+            ii, jj = np.meshgrid(np.arange(1, m + 2), np.arange(1, n + 2), indexing="ij")
+            cnt, sm = hip.wsum_query(h, dt, ii.ravel(), jj.ravel(), unsigned=True)
+            hip.wsum_free(h)
+            assert np.array_equal(sm.reshape(m + 1, n + 1), P), (m, n)
+            Cn = np.zeros((m + 1, n + 1), dtype=np.int64); Cn[1:, 1:] = np.cumsum(np.cumsum(D != 0, axis=0), axis=1)
+            assert np.array_equal(cnt.reshape(m + 1, n + 1), Cn)
+        # rooks: one point per column
+        N = m
+        idx = rng.permutation(N) + 1
+        val = rng.integers(0, 2 ** 63, N, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        B = np.zeros((N, N), dtype=np.uint64)
+        B[idx - 1, np.arange(N)] = val
+        P = np.zeros((N + 1, N + 1), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            P[1:, 1:] = np.cumsum(np.cumsum(B, axis=0, dtype=np.uint64), axis=1, dtype=np.uint64)
+        Cn = np.zeros((N + 1, N + 1), dtype=np.int64); Cn[1:, 1:] = np.cumsum(np.cumsum(B != 0, axis=0), axis=1)
+        ii, jj = np.meshgrid(np.arange(1, N + 2), np.arange(1, N + 2), indexing="ij")
+        for v in (val, None):
+            h, dt = hip.rook_build(N, idx, v)
+            cnt, sm = hip.wsum_query(h, dt, ii.ravel(), jj.ravel(), unsigned=True)
+            hip.wsum_free(h)
+            assert np.array_equal(cnt.reshape(N + 1, N + 1), Cn), N
+            if v is not None:
+                assert np.array_equal(sm.reshape(N + 1, N + 1), P), N
+    # Float64 weights: equal up to rounding
+    A = sprand(40, 50, 0.3, rng)
+    val = rng.random(A.nnz)
+    D = np.zeros((40, 50)); D[A.rowval - 1, np.repeat(np.arange(50), np.diff(A.colptr))] = val
+    P = np.zeros((41, 51)); P[1:, 1:] = np.cumsum(np.cumsum(D, axis=0), axis=1)
+    h, dt = hip.domsum_build(A, val)
+    ii, jj = np.meshgrid(np.arange(1, 42), np.arange(1, 52), indexing="ij")
+    cnt, sm = hip.wsum_query(h, dt, ii.ravel(), jj.ravel())
+    hip.wsum_free(h)
+    assert np.allclose(sm.reshape(41, 51), P, rtol=1e-12, atol=1e-12)
