@@ -194,7 +194,10 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
         if (b > tau && b < nbits && (allp || ((r >> b) & 1))) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
 }
 
-// Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads; wave-reduced counters.
+// Larger ranges: one wave per (row, chunk of CH columns); coalesced 64-entry loads.  The row -- hence every threshold -- is
+// wave-uniform: thresholds live in SGPRs, a plane's count of 64 entries is ONE vector compare into a lane mask plus a scalar
+// popcount and add (s_bcnt1 / s_add on the scalar unit), and the wave total needs no cross-lane reduction at the end.
+// (Round 1 kept per-lane counters: a compare and an add per entry and plane on the vector unit, 6 shuffles per plane to finish.)
 template <bool ge>
 __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, int chunks_per_row, int ch_cols,
                                                     const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
@@ -213,6 +216,7 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
     if (c1 > r) c1 = r;
     int32_t thr[NBMAX], cnt[NBMAX];
     int64_t prL = PR(rL);
+    uint32_t act = 0;                                          // planes of this row (wave-uniform)
 #pragma unroll
     for (int b = 0; b < NBMAX; b++) {                          // loads issued back to back; addresses are wave-uniform
         cnt[b] = 0;
@@ -220,30 +224,30 @@ __global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t 
         if (b <= tau || b >= nbits) continue;
         bool on = allp || ((r >> b) & 1);
         int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
-        if (on) thr[b] = v;
+        if (on) { thr[b] = __builtin_amdgcn_readfirstlane(v); act |= 1u << b; }
     }
+    act = __builtin_amdgcn_readfirstlane(act);
     int64_t q0 = pos[c0], q1 = pos[c1];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
-    for (int64_t q = q0 + lane; q < q1; q += 256) {            // four independent coalesced loads in flight (eight: no faster)
-        int32_t v0 = prev[q], v1 = q + 64 < q1 ? prev[q + 64] : NEVER, v2 = q + 128 < q1 ? prev[q + 128] : NEVER,
+    // (Tried: four 16-byte loads per lane and 1024 entries per iteration -- 101 VGPRs, occupancy 4, 18 % slower.)
+    for (int64_t qb = q0; qb < q1; qb += 256) {                // (a wave-uniform trip count keeps the counters on the scalar unit)
+        const int64_t q = qb + lane;                           // four independent coalesced loads in flight (eight: no faster)
+        int32_t v0 = q < q1 ? prev[q] : NEVER, v1 = q + 64 < q1 ? prev[q + 64] : NEVER, v2 = q + 128 < q1 ? prev[q + 128] : NEVER,
                 v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
 #pragma unroll
         for (int b = 0; b < NBMAX; b++) {
-            if (b <= tau || b >= nbits || !(allp || ((r >> b) & 1))) continue;      // wave-uniform: only the planes of this row's set bits
-            int32_t t = thr[b];
-            cnt[b] += ge ? ((v0 >= t) + (v1 >= t) + (v2 >= t) + (v3 >= t)) : ((v0 < t) + (v1 < t) + (v2 < t) + (v3 < t));
+            if (!((act >> b) & 1)) continue;                    // scalar branch: only the planes of this row
+            const int32_t t = thr[b];
+            cnt[b] += (int32_t)(ge ? (__popcll(__ballot(v0 >= t)) + __popcll(__ballot(v1 >= t)) + __popcll(__ballot(v2 >= t)) + __popcll(__ballot(v3 >= t)))
+                                   : (__popcll(__ballot(v0 < t)) + __popcll(__ballot(v1 < t)) + __popcll(__ballot(v2 < t)) + __popcll(__ballot(v3 < t))));
         }
     }
+    if (lane == 0) {
 #pragma unroll
-    for (int b = 0; b < NBMAX; b++) {
-        bool on = b > tau && b < nbits && (allp || ((r >> b) & 1));          // wave-uniform
-        if (on) {
-            int32_t c = cnt[b];
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-            if (lane == 0) {
-                if (chunks_per_row == 1) cr[(int64_t)b * n1 + PR(r)] = c;
-                else atomicAdd(&cr[(int64_t)b * n1 + PR(r)], c);
-            }
+        for (int b = 0; b < NBMAX; b++) {
+            if (!((act >> b) & 1)) continue;
+            if (chunks_per_row == 1) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
+            else atomicAdd(&cr[(int64_t)b * n1 + PR(r)], cnt[b]);
         }
     }
 }
