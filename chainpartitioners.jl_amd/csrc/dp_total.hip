@@ -27,6 +27,9 @@
 //            shuffles, evaluated and arg-min reduced per task;
 //          - tasks spanning tiles are merged by k_span_short (one lane), or k_open + k_fix (work lists).
 //  * plane arrays are stored level-major (prow): the rows of one round are contiguous in every plane.
+//  * width-windowed layers (candidates max(0, r - w) <= p <= r: the ConstrainedCost DP, DynamicSplitter.jl:206-258) run the same
+//    kernels on another tiling of the candidates: every row has a task in every plane b <= floor(log2 w) -- standard, common
+//    and mirrored blocks, see struct Geo below and DESIGN.md section 4b.
 #include "csr.hpp"
 #include "model.hpp"
 #include "dp.hpp"
