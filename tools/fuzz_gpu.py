@@ -51,8 +51,8 @@ while time.time() - t0 < budget:
     A = rand_matrix(); f = rand_model(); K = int(rng.choice([1, 2, 3, 5, 8, 17]))
     tag = (A.m, A.n, A.nnz, type(f).__name__, f._params(), K)
     meths = [cp.DynamicTotalSplitter(f), cp.DynamicTotalChunker(f)]
-    if A.n <= 1500:
-        meths += [cp.DynamicBottleneckSplitter(f)]
+    if A.n <= 1500 or (all(p >= 0 for p in f._params()[1:]) and not isinstance(f, cp.AffineHyperedgeCutModel)):
+        meths += [cp.DynamicBottleneckSplitter(f)]          # (valley search for growing costs at any n; general sweep below 1500)
     if isinstance(f, (cp.AffineConnectivityModel, cp.AffineWorkModel)) and all(p >= 0 for p in f._params()) and sum(f._params()) > 0:
         meths += [cp.BisectCostBottleneckSplitter(f, 0.01), cp.BisectIndexBottleneckSplitter(f)]
         if isinstance(f, cp.AffineConnectivityModel):
@@ -61,6 +61,17 @@ while time.time() - t0 < budget:
         got = cp.partition_stripe(A, K, meth, backend=hip)
         want = cp.partition_stripe(A, K, meth, backend=orc)
         assert got == want, ("partition", type(meth).__name__, tag)
+    # the width-constrained K-part DP (windowed path for the inverse-Monge models, one-wave kernel otherwise), both loop orders;
+    # windows from "barely feasible" to "wider than the matrix"
+    if A.n >= 1 and A.n <= 2500:
+        for w in (max(1, -(-A.n // K) + int(rng.integers(0, 4))), max(1, int(rng.integers(1, A.n + 3)))):
+            fc = cp.ConstrainedCost(f, cp.VertexCount(), w)
+            for meth in (cp.DynamicTotalSplitter(fc), cp.DynamicTotalChunker(fc)):
+                if meth.order == 1 and getattr(f, "alpha_k", None) is not None:
+                    continue
+                got = cp.partition_stripe(A, K, meth, backend=hip)
+                want = cp.partition_stripe(A, K, meth, backend=orc)
+                assert got == want, ("constrained", type(meth).__name__, w, tag)
     if A.n >= 1:
         for w in (int(rng.integers(1, 20)),):
             fc = cp.ConstrainedCost(f, cp.VertexCount(), w)
