@@ -63,10 +63,24 @@ __global__ void __launch_bounds__(1024) k_bn_run1(int64_t n1, const TC *__restri
     if (p < n1) runend[p] = s_end[threadIdx.x];            // INT32_MAX: the run continues into the next block
     if (threadIdx.x == 0) blk_first_end[blockIdx.x] = s_end[0];
 }
-__global__ void k_bn_run2(int64_t nblk, int32_t *__restrict__ blk_first_end)
+__global__ void __launch_bounds__(1024) k_bn_run2(int64_t nblk, int32_t *__restrict__ blk_first_end)
 {
-    // blk_first_end[b] = end of the run that starts (or continues) at the first row of block b; resolved from the right
-    for (int64_t b = nblk - 2; b >= 0; b--) if (blk_first_end[b] == INT32_MAX) blk_first_end[b] = blk_first_end[b + 1];
+    // blk_first_end[b] = end of the run that starts (or continues) at the first row of block b: a suffix minimum over the blocks
+    // (INT32_MAX = "continues"), one workgroup: every thread owns a contiguous share, suffix minima of the shares' minima, fill
+    __shared__ int32_t sh[1024];
+    const int64_t per = (nblk + 1023) / 1024, lo = (int64_t)threadIdx.x * per, hi = lo + per < nblk ? lo + per : nblk;
+    int32_t m = INT32_MAX;
+    for (int64_t b = hi - 1; b >= lo; b--) if (blk_first_end[b] < m) m = blk_first_end[b];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int32_t v = threadIdx.x + o < 1024 ? sh[threadIdx.x + o] : INT32_MAX;
+        __syncthreads();
+        if (v < sh[threadIdx.x]) sh[threadIdx.x] = v;
+        __syncthreads();
+    }
+    int32_t run = threadIdx.x + 1 < 1024 ? sh[threadIdx.x + 1] : INT32_MAX;      // minimum over the shares to the right
+    for (int64_t b = hi - 1; b >= lo; b--) { if (blk_first_end[b] == INT32_MAX) blk_first_end[b] = run; else run = blk_first_end[b]; }
 }
 __global__ void __launch_bounds__(1024) k_bn_run3(int64_t n1, int64_t nblk, int32_t *__restrict__ runend, const int32_t *__restrict__ blk_first_end)
 {
@@ -84,27 +98,79 @@ __device__ __forceinline__ void bn_counts(const BnCtx<TC> &C, int64_t p, int64_t
     if (C.hyp) nl = wt_count_le(C.self, C.n - p, C.lpos[r]);
 }
 
-// first row of every chunk: its crossing by binary search (the predicate W[p] >= f(p, r) is monotone in p)
+// first row of every chunk: its crossing by binary search (the predicate W[p] >= f(p, r) is monotone in p).  The crossing is
+// non-decreasing in the row, so the search runs coarse to fine: every 64th chunk start over the whole range first (stride 64,
+// phase 0), then the others between the crossings of their coarse neighbours (phase 1) -- a handful of probes instead of log2(n).
 template <typename TC>
-__global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk,
-                                                   int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0)
+__device__ __forceinline__ bool bn_pred(const BnCtx<TC> &C, int64_t p, int64_t r)      // W[p] >= f(p, r)   (p <= r)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunk) return;
+    int64_t nn, nl;
+    bn_counts(C, p, r, nn, nl);
+    return C.W[p] >= bn_cost(C, p, r, nn, nl);
+}
+
+// hint (phase 0 only, may be null): the crossings of the same rows in the previous layer.  Layers converge, so the search gallops
+// away from the hint -- two probes where the crossing did not move, 2 log2(distance) where it did -- instead of bisecting the
+// whole range; any hint is safe (it only chooses where the search starts).
+template <typename TC>
+__global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk, int phase,
+                                                   int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0,
+                                                   const int32_t *__restrict__ hint)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (phase == 0) t *= 64;
+    if (t >= nchunk || (phase == 1 && (t & 63) == 0)) return;
     const int64_t r = rlo + t * CH;
-    int64_t lo = 0, hi = r + 1;                             // the answer lies in [0, r + 1]
+    int64_t lo = 0, hi = r + 1;                             // the answer lies in [lo, hi]; pred is true at hi (r + 1: "no crossing")
+    if (phase == 1) {
+        const int64_t tl = t & ~(int64_t)63, tr = tl + 64;
+        lo = c0[tl];                                        // c(r) >= c(left coarse row)
+        if (tr < nchunk && (int64_t)c0[tr] < hi) hi = c0[tr];      // c(r) <= c(right coarse row)
+        if (lo > hi) lo = hi;
+    } else if (hint) {
+        int64_t g = hint[t];
+        if (g < 0) g = 0;
+        if (g > r) g = r;
+        if (bn_pred(C, g, r)) {                             // the crossing is at or left of g: gallop left
+            hi = g;
+            int64_t d = 1;
+            while (hi - d >= 0 && bn_pred(C, hi - d, r)) { hi -= d; d <<= 1; }
+            lo = hi - d >= 0 ? hi - d + 1 : 0;
+        } else {                                            // right of g
+            int64_t cur = g, d = 1;
+            while (cur + d <= r && !bn_pred(C, cur + d, r)) { cur += d; d <<= 1; }
+            lo = cur + 1;
+            if (cur + d <= r) hi = cur + d;
+        }
+    }
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;                 // mid <= r
-        int64_t nn, nl;
-        bn_counts(C, mid, r, nn, nl);
-        if (C.W[mid] >= bn_cost(C, mid, r, nn, nl)) hi = mid; else lo = mid + 1;
+        if (bn_pred(C, mid, r)) hi = mid; else lo = mid + 1;
     }
     int64_t nn = 0, nl = 0;
     if (lo <= r) bn_counts(C, lo, r, nn, nl);
     c0[t] = (int32_t)lo; nn0[t] = (int32_t)nn; nl0[t] = (int32_t)nl;
 }
 
+// a lane's pass over one column: eight independent loads in flight (a loop of single loads pays one memory latency per entry --
+// ~30 per row -- and that chain, not bandwidth or divergence, was the whole cost of the walk)
+template <bool GE>
+__device__ __forceinline__ int32_t bn_scan(const int32_t *__restrict__ arr, int32_t q0, int32_t q1, int32_t thr)
+{
+    int32_t c = 0;
+    for (int32_t q = q0; q < q1; q += 8) {
+        int32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = q + k < q1 ? arr[q + k] : (GE ? INT32_MIN : INT32_MAX);
+#pragma unroll
+        for (int k = 0; k < 8; k++) c += GE ? (v[k] >= thr) : (v[k] < thr);
+    }
+    return c;
+}
+
 // one lane per chunk: the two-pointer walk
+// (Tried: the walk as a per-lane state machine -- one loop per lane consuming entries of whatever scan the lane is in, so that a
+//  wave does not wait for its longest column at every scan: 1.5x slower; the cost was the serial loads, not the divergence.)
 template <typename TC>
 __global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk,
                                                  const int32_t *__restrict__ c0, const int32_t *__restrict__ nn0, const int32_t *__restrict__ nl0,
@@ -121,15 +187,15 @@ __global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64
         if (r > r0) {
             // column r - 1 joins the part [c, r - 1) on the right (an empty part stays empty when c == r)
             if (c <= r - 1) {
-                if (nets) for (int32_t q = C.pos32[r - 1], q1 = C.pos32[r]; q < q1; q++) nn += (C.prev[q] < c);
-                if (C.hyp) for (int32_t q = C.lpos32[r - 1], q1 = C.lpos32[r]; q < q1; q++) nl += (C.lfirst[q] >= c);
+                if (nets) nn += bn_scan<false>(C.prev, C.pos32[r - 1], C.pos32[r], c);
+                if (C.hyp) nl += bn_scan<true>(C.lfirst, C.lpos32[r - 1], C.lpos32[r], c);
             }
             // the crossing only moves right
             while (c <= r) {
                 if (!(C.W[c] < bn_cost(C, c, r, nn, nl))) break;
                 if (c < r) {                                // column c leaves on the left
-                    if (nets) for (int32_t q = C.pos32[c], q1 = C.pos32[c + 1]; q < q1; q++) nn -= (C.next[q] >= r);
-                    if (C.hyp) for (int32_t q = C.fpos32[c], q1 = C.fpos32[c + 1]; q < q1; q++) nl -= (C.flast[q] < r);
+                    if (nets) nn -= bn_scan<true>(C.next, C.pos32[c], C.pos32[c + 1], r);
+                    if (C.hyp) nl -= bn_scan<false>(C.flast, C.fpos32[c], C.fpos32[c + 1], r);
                 }
                 c++;
             }
@@ -142,8 +208,8 @@ __global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64
             int32_t a = 0, al = 0;
             if (c - 1 < r) {
                 a = nn; al = nl;
-                if (nets) for (int32_t q = C.pos32[c - 1], q1 = C.pos32[c]; q < q1; q++) a += (C.next[q] >= r);
-                if (C.hyp) for (int32_t q = C.fpos32[c - 1], q1 = C.fpos32[c]; q < q1; q++) al += (C.flast[q] < r);
+                if (nets) a += bn_scan<true>(C.next, C.pos32[c - 1], C.pos32[c], r);
+                if (C.hyp) al += bn_scan<false>(C.flast, C.fpos32[c - 1], C.fpos32[c], r);
             }
             fm = bn_cost(C, c - 1, r, a, al);
         }
@@ -157,7 +223,8 @@ __global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64
 struct BnWork {
     bool have_net = false, have_self = false;
     WaveletHost net, self;
-    DBuf<int32_t> runend, blk, c0, nn0, nl0;
+    DBuf<int32_t> runend, blk, c0, nn0, nl0, hint;
+    int64_t hint_rlo = -1, hint_nchunk = -1, hint_ch = -1;      // the tiling the hints belong to (-1: none)
 };
 
 static BnWork *bn_work_get(cp_csr_s *A)
@@ -165,7 +232,7 @@ static BnWork *bn_work_get(cp_csr_s *A)
     if (!A->bn_work) {
         A->bn_work = new BnWork();
         A->bn_work_free_fn = [](void *w) { delete reinterpret_cast<BnWork *>(w); };
-        A->bn_work_reset_fn = [](void *w) { auto *B = reinterpret_cast<BnWork *>(w); B->have_net = false; B->have_self = false; };   // (cp_csr_reset_cache)
+        A->bn_work_reset_fn = [](void *w) { auto *B = reinterpret_cast<BnWork *>(w); B->have_net = false; B->have_self = false; B->hint_nchunk = -1; };   // (cp_csr_reset_cache)
     }
     return reinterpret_cast<BnWork *>(A->bn_work);
 }
@@ -198,9 +265,16 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     B->c0.ensure((size_t)nchunk); B->nn0.ensure((size_t)nchunk); B->nl0.ensure((size_t)nchunk);
     ProfScope ps(PROF_BRUTE, s, 8.0 * (double)A->N + 24.0 * (double)(rhi - rlo + 1));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_run1<TC>), dim3((unsigned)nblk), dim3(1024), 0, s, n1, W, B->runend.p, B->blk.p);
-    hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1), 0, s, nblk, B->blk.p);
+    hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1024), 0, s, nblk, B->blk.p);
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p);
+    const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
+    B->hint.ensure((size_t)nchunk);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 0, B->c0.p, B->nn0.p, B->nl0.p,
+                       hinted ? B->hint.p : (const int32_t *)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, B->c0.p, B->nn0.p, B->nl0.p,
+                       (const int32_t *)nullptr);
+    CP_HIP(hipMemcpyAsync(B->hint.p, B->c0.p, sizeof(int32_t) * (size_t)nchunk, hipMemcpyDeviceToDevice, s));
+    B->hint_nchunk = nchunk; B->hint_rlo = rlo; B->hint_ch = CH;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
                        B->runend.p, cst_out, ptr_out);
     CP_HIP(hipGetLastError());

@@ -21,10 +21,16 @@ static int32_t cllog2_i(int64_t x)      // util.jl:3-8 : ceil(log2(x)), cllog2(1
     return h;
 }
 
-__global__ void k_hist_keys(const int32_t *__restrict__ keys, int64_t Nk, int32_t *__restrict__ hist)
+// hot: a key that a large share of the entries carries (net keys: n + 1 = "no previous occurrence", one entry in ten on the bench
+// matrices) -- same-address atomics serialise in L2 (115 ms of a 270 ms build at N = 10^8), so its count is taken per wave
+__global__ void __launch_bounds__(256) k_hist_keys(const int32_t *__restrict__ keys, int64_t Nk, int32_t *__restrict__ hist, int32_t hot)
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < Nk) atomicAdd(&hist[keys[q]], 1);
+    const int32_t key = q < Nk ? keys[q] : -1;
+    const bool is_hot = key >= 0 && key == hot;
+    const unsigned long long m = __ballot(is_hot);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&hist[hot], (int32_t)__popcll(m));
+    if (key >= 0 && !is_hot) atomicAdd(&hist[key], 1);
 }
 
 __global__ void __launch_bounds__(256) k_wt_bits(const int32_t *__restrict__ keys, int64_t Nk, int h, int64_t W,
@@ -58,7 +64,7 @@ __global__ void __launch_bounds__(256) k_wt_scatter(const int32_t *__restrict__ 
     out[np] = key;
 }
 
-void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s)
+void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key)
 {
     ProfScope ps(PROF_WAVELET, s, 8.0 * (double)Nk * (double)H);
     int64_t W = 1 + cdiv(Nk, 64);
@@ -72,7 +78,7 @@ void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, 
     DBuf<int32_t> hist((size_t)nkeys), popc((size_t)W), tmp((size_t)(Nk > 0 ? Nk : 1));
     DBuf<int64_t> scratch;
     CP_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), s));
-    if (Nk > 0) hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p);
+    if (Nk > 0) hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p, hot_key);
     exclusive_scan_i32_i32(hist.p, WT.qos0.p, nkeys, scratch, s);
     int32_t *cur = keys.p, *oth = tmp.p;
     for (int h = H; h >= 1 && Nk > 0; h--) {
@@ -246,7 +252,7 @@ static void wsum_build(cp_wsum_s *Wd, DBuf<int32_t> &keys, const TW *w_dev, int6
     CP_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), s));
     if (Nk > 0) {
         CP_HIP(hipMemcpyAsync(wa.p, w_dev, sizeof(TW) * (size_t)Nk, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p);
+        hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p, (int32_t)-1);
     }
     exclusive_scan_i32_i32(hist.p, WT.qos0.p, nkeys, scratch, s);
     int32_t *cur = keys.p, *oth = tmp.p;
@@ -299,7 +305,7 @@ void ensure_net_counter(cp_csr_s *A, WaveletHost &out)
     int64_t N = A->N;
     DBuf<int32_t> keys((size_t)(N > 0 ? N : 1));
     if (N > 0) hipLaunchKernelGGL(k_keys_net, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, A->prev.p, keys.p, N, (int32_t)A->n);
-    wavelet_build(out, keys, N, cllog2_i(A->n + 2), s);
+    wavelet_build(out, keys, N, cllog2_i(A->n + 2), s, (int32_t)(A->n + 1));      // key n + 1: the first occurrence of a row
 }
 void ensure_selfnet_counter(cp_csr_s *A, WaveletHost &out)
 {

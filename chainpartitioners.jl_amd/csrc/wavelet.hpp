@@ -51,7 +51,7 @@ struct WaveletHost {
 };
 
 // keys: device int32 array of Nk values in [0, 2^H); destroyed (used as scratch)
-void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s);
+void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key = -1);      // hot_key: a key many entries share (counted per wave)
 
 }  // namespace cpk
 
