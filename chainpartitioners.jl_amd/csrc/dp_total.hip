@@ -2585,7 +2585,9 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         // another row tile than the layer the counts come from: the unconstrained driver keeps its tile, the constrained one moves
         // a window over the rows -- take the prediction per row of the tile
         const double a = (double)(Wk.pred_rhi - Wk.pred_rlo + 1), b = (double)(rhi - rlo + 1);
-        if (!G.win || a < 1 || b < 1) spec = false;
+        // (a much larger tile than the counts come from -- the one-row last layer of an earlier call on this handle -- would
+        //  scale a handful of tasks into buffers of any size: such a layer takes its exact counts instead)
+        if (!G.win || a < 1 || b < 1 || b > 2.0 * a) spec = false;
         else Wk.pred_scale = b / a;
     }
     if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;

@@ -114,3 +114,53 @@ def test_fast_scheme_equals_literal_device_sweep_at_2e5(hip):
                 hip.set_option("force_brute", 0)
             assert rc1 == 0 and rc2 == 0, hip.last_error()
             assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (A, mdl)
+
+
+def test_config3_shape_constrained_and_bottleneck_dps(hip):
+    """n = 10^7 / nnz = 10^8: the two DPs whose answers are NOT closed-form.
+      * width-constrained total DP (bin/test_table_constrained_splits.jl:28): every part within w_max, no worse than the
+        full-width feasible partition, and the same split vector whatever driver options size the speculative layers;
+      * bottleneck DP: its value equals the exact BisectIndex optimum, and it does not depend on the chunking of the walk."""
+    from bench import gen_suitesparse_shaped
+    n, N, K = 10_000_000, 100_000_000, 16
+    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 2, torch.device("cuda", 0))
+    h = _handle(hip, n, colptr, rowval)
+    try:
+        mdl = cp.AffineConnectivityModel(0, 0, 0, 1)
+        mm = mdl.marshal(); wm = cp.VertexCount().marshal()
+        w = -(-3 * n // (2 * K))
+        spl = np.zeros(K + 1, dtype=np.int64)
+        assert hip.partition_dynamic(h, K, 0, 0, mm, None, wm, w, float(w), spl) == 0, hip.last_error()
+        assert spl[0] == 1 and spl[-1] == n + 1 and np.all(np.diff(spl) >= 0) and int(np.diff(spl).max()) <= w
+        assert len(set(spl.tolist())) > K // 2
+        rc, got = hip.objective(h, K, spl, mm, None, 0)
+        full = np.minimum(1 + w * np.arange(K + 1, dtype=np.int64), n + 1)
+        rc, ref = hip.objective(h, K, full, mm, None, 0)
+        assert got <= ref
+        for opts in ({"nospec": 1}, {"gap_tau": -1}):
+            for k_, v_ in opts.items():
+                hip.set_option(k_, v_)
+            try:
+                spl2 = np.zeros(K + 1, dtype=np.int64)
+                assert hip.partition_dynamic(h, K, 0, 0, mm, None, wm, w, float(w), spl2) == 0, (opts, hip.last_error())
+            finally:
+                hip.set_option("nospec", 0); hip.set_option("gap_tau", 5)
+            assert np.array_equal(spl, spl2), opts
+        # the chunker loop order fills the same tables
+        spl3 = np.zeros(K + 1, dtype=np.int64)
+        assert hip.partition_dynamic(h, K, 0, 1, mm, None, wm, w, float(w), spl3) == 0
+        assert np.array_equal(spl, spl3)
+        net = cp.AffineConnectivityModel(0, 10, 1, 100).marshal()
+        b1 = np.zeros(K + 1, dtype=np.int64); b2 = np.zeros(K + 1, dtype=np.int64); bi = np.zeros(K + 1, dtype=np.int64)
+        assert hip.partition_dynamic(h, K, 1, 0, net, None, None, 0, 0.0, b1) == 0, hip.last_error()
+        hip.set_option("bn_chunk", 64)
+        try:
+            assert hip.partition_dynamic(h, K, 1, 0, net, None, None, 0, 0.0, b2) == 0
+        finally:
+            hip.set_option("bn_chunk", 8)
+        assert np.array_equal(b1, b2)
+        assert hip.partition_bisect_index(h, K, net, 0, bi) == 0
+        v1 = hip.objective(h, K, b1, net, None, 1)[1]; vi = hip.objective(h, K, bi, net, None, 1)[1]
+        assert v1 == vi and len(set(b1.tolist())) > K // 2
+    finally:
+        hip.csr_destroy(h)
