@@ -368,7 +368,7 @@ void ensure_links(cp_csr_s *A)
     int64_t N = A->N, n = A->n, m = A->m;
     size_t Na = (size_t)(N > 0 ? N : 1);
     ProfScope ps(PROF_LINKS, s, 8.0 * (double)N + 8.0 * (double)(n + 1));
-    A->col.ensure(Na); A->prev.ensure(Na + 8); A->next.ensure(Na + 8);     // +8: 16-byte vector loads may over-read the tail
+    A->col.ensure(Na); A->prev.ensure(Na + 16); A->next.ensure(Na + 16);   // +16: vector loads may over-read the tail
     A->rfirst.ensure((size_t)(m > 0 ? m : 1)); A->rlast.ensure((size_t)(m > 0 ? m : 1));
     A->tpos.ensure((size_t)m + 1); A->tq.ensure(Na);
     A->pos32.ensure((size_t)n + 1);
@@ -438,7 +438,7 @@ void ensure_self(cp_csr_s *A)
     CP_HIP(hipMemcpyAsync(&tot, A->fpos.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     A->nrows_nonempty = tot;
-    A->flast.ensure((size_t)(tot > 0 ? tot : 1) + 8); A->lfirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);   // +8: vector over-read
+    A->flast.ensure((size_t)(tot > 0 ? tot : 1) + 16); A->lfirst.ensure((size_t)(tot > 0 ? tot : 1) + 16);   // +16: vector over-read
     A->ffirst.ensure((size_t)(tot > 0 ? tot : 1) + 8);
     CP_HIP(hipMemsetAsync(cf.p, 0, cf.bytes(), s));
     CP_HIP(hipMemsetAsync(cl.p, 0, cl.bytes(), s));

@@ -146,10 +146,10 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 // wave are skipped with a wave-uniform test (about half of them).
 // (Tried: deciding all planes but one by the position of the link value among the Fenwick blocks, with lane-private LDS
 //  histograms -- 4x fewer VALU instructions but 300 B of LDS per row leave 2 waves per SIMD: slower.)
-template <bool ge>
+template <bool ge, int NB>
 __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ prev, const int32_t *__restrict__ opt,
-                                                     int32_t *__restrict__ cr, int allp)
+                                                     int32_t *__restrict__ cr, int allp, int cap)
 {
     // allp (windowed layers): every row takes part in every plane tau < b < nbits (an empty block holds the threshold -1 or a
     // stale value: its count is never read)
@@ -160,12 +160,12 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
     if (r > n) live = false;
     if (!live) r = 0;                                          // no bits: takes part in the ballots only
     int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
-    int32_t thr[NBMAX], cnt[NBMAX];
+    int32_t thr[NB], cnt[NB];
     uint32_t used = 0;                                         // planes with a set bit somewhere in the wave (uniform)
     int64_t prL = live ? PR(rL) : 0;
     // all threshold loads are issued back to back (a lane without bit b reads a valid dummy slot): one memory latency, not 23
 #pragma unroll
-    for (int b = 0; b < NBMAX; b++) {
+    for (int b = 0; b < NB; b++) {
         cnt[b] = 0;
         thr[b] = ge ? INT32_MAX : INT32_MIN;
         if (b <= tau || b >= nbits) continue;                  // wave-uniform
@@ -175,15 +175,32 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
         int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
         if (on) thr[b] = v;
     }
-    if (!live) return;
-    int64_t q0 = pos[rL], q1 = pos[r];
+    // Degrees vary a lot (the bench matrix: mean 10, one column in a hundred above 60) and a wave steps as often as its longest
+    // lane: every lane takes the first `cap` entries of its row on its own, sixteen per step, and what a row has beyond them
+    // is counted by the whole wave, 64 entries per coalesced load with the row's thresholds broadcast (the k_rpass_wave scheme).
+    int64_t q0 = 0;
+    int32_t len = 0;
+    if (live) { q0 = pos[rL]; len = (int32_t)(pos[r] - q0); }
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
-    for (int64_t q = q0; q < q1; q += 16) {                    // sixteen independent loads in flight per lane
+    const int32_t mlen = len < cap ? len : cap;
+    for (int32_t o = 0; o < mlen; o += 16) {                   // sixteen entries in flight per lane
         int32_t v[16];
+        // four 16-byte loads (dword-aligned: the global path takes unaligned vectors; the link arrays carry 16 entries of
+        // slack) instead of sixteen 4-byte ones: every lane reads another cache line, and the L1 takes a line per lane and
+        // instruction whatever its width
+        struct __attribute__((packed, aligned(4))) V4 { int32_t a, b, c, d; };
+        const V4 *pv = reinterpret_cast<const V4 *>(prev + q0 + o);
+        const int32_t rem = mlen - o;
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = q + j < q1 ? prev[q + j] : NEVER;
+        for (int j = 0; j < 4; j++) {
+            V4 t = {NEVER, NEVER, NEVER, NEVER};
+            if (4 * j < rem) t = pv[j];
+            v[4 * j] = t.a; v[4 * j + 1] = t.b; v[4 * j + 2] = t.c; v[4 * j + 3] = t.d;
+        }
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) {
+        for (int j = 0; j < 16; j++) v[j] = j < rem ? v[j] : NEVER;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
             if (!((used >> b) & 1)) continue;                  // wave-uniform
             int32_t t = thr[b];
             int32_t c = 0;
@@ -192,8 +209,34 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
             cnt[b] += c;
         }
     }
+    {
+        const int lane = threadIdx.x & 63;
+        uint32_t mypl = 0;                                     // the planes this lane's row takes part in
+        if (live)
+            for (int b = tau + 1; b < nbits; b++) if (allp || ((r >> b) & 1)) mypl |= 1u << b;
+        uint64_t rest = __ballot(len > cap);
+        const int32_t q0lo = (int32_t)(uint32_t)q0, q0hi = (int32_t)(q0 >> 32);
+        while (rest) {                                         // wave-uniform
+            const int src = __ffsll((unsigned long long)rest) - 1;
+            rest &= rest - 1;
+            const int64_t a = (((int64_t)__builtin_amdgcn_readlane(q0hi, src) << 32) | (uint32_t)__builtin_amdgcn_readlane(q0lo, src)) + cap;
+            const int32_t ln = __builtin_amdgcn_readlane(len, src) - cap;
+            const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int32_t)mypl, src);
+            for (int32_t o = 0; o < ln; o += 64) {
+                const int32_t v = o + lane < ln ? prev[a + o + lane] : NEVER;
 #pragma unroll
-    for (int b = 0; b < NBMAX; b++)
+                for (int b = 0; b < NB; b++) {
+                    if (!((pl >> b) & 1)) continue;            // scalar branch
+                    const int32_t t = __builtin_amdgcn_readlane(thr[b], src);
+                    const int32_t c = (int32_t)__popcll(__ballot(ge ? (v >= t) : (v < t)));
+                    if (lane == src) cnt[b] += c;
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
         if (b > tau && b < nbits && (allp || ((r >> b) & 1))) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
 }
 
@@ -201,57 +244,75 @@ __global__ void __launch_bounds__(256) k_rpass_small(int tau, int nbits, int64_t
 // wave-uniform: thresholds live in SGPRs, a plane's count of 64 entries is ONE vector compare into a lane mask plus a scalar
 // popcount and add (s_bcnt1 / s_add on the scalar unit), and the wave total needs no cross-lane reduction at the end.
 // (Round 1 kept per-lane counters: a compare and an add per entry and plane on the vector unit, 6 shuffles per plane to finish.)
-template <bool ge>
-__global__ void __launch_bounds__(256) k_rpass_wave(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, int chunks_per_row, int ch_cols,
-                                                    const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
-                                                    const int32_t *__restrict__ opt, int32_t *__restrict__ cr, int allp)
+template <bool ge, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_rpass_wave(int tau, int nbits, int64_t n, int64_t u0, int64_t nrows, int chunks_per_row, int ch_cols,
+                                                         const int64_t *__restrict__ pos, const int32_t *__restrict__ prev,
+                                                         const int32_t *__restrict__ opt, int32_t *__restrict__ cr, int allp)
 {
-    int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // WPB > 1 (the host gives such a block WPB chunks of ONE row: chunks_per_row % WPB == 0): the waves add their counts in
+    // LDS and one of them updates the row.  Thousands of chunks of a row of a high round each sending an atomic to the same
+    // dozen addresses cost 35 ns apiece, one after the other: 70 us of an 85 us pass.
+    int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     int64_t u = w / chunks_per_row;
     int ck = (int)(w - u * chunks_per_row);
-    if (u >= nrows) return;
+    if (u >= nrows) return;                                    // (block-uniform when WPB > 1)
     u += u0;
     int64_t r = ((u << 1) | 1) << tau;
     if (r > n) return;
     int64_t n1 = n + 1, rL = r - ((int64_t)1 << tau);
     int64_t c0 = rL + (int64_t)ck * ch_cols, c1 = c0 + ch_cols;
     if (c1 > r) c1 = r;
-    int32_t thr[NBMAX], cnt[NBMAX];
     int64_t prL = PR(rL);
-    uint32_t act = 0;                                          // planes of this row (wave-uniform)
-#pragma unroll
-    for (int b = 0; b < NBMAX; b++) {                          // loads issued back to back; addresses are wave-uniform
-        cnt[b] = 0;
-        thr[b] = ge ? INT32_MAX : INT32_MIN;
-        if (b <= tau || b >= nbits) continue;
-        bool on = allp || ((r >> b) & 1);
-        int32_t v = opt[(int64_t)b * n1 + (on ? prL : 0)];
-        if (on) { thr[b] = __builtin_amdgcn_readfirstlane(v); act |= 1u << b; }
-    }
+    // planes of this row (wave-uniform).  Lane b holds plane b: it fetches the plane's threshold (ONE vector memory instruction
+    // for the row -- a uniform-address load per plane cost a dozen), keeps its count and stores it at the end.  The counting
+    // loop walks the set bits of `act`: v_readlane hands the threshold to the scalar side, a plane's count of 64 entries is one
+    // vector compare into a lane mask and a scalar popcount.  (Thresholds and counts in scalar register ARRAYS, one slot per
+    // plane, spilled 40-110 SGPRs into vector lanes and paid a skipped branch for every plane the row does not have.)
+    uint32_t act = 0;
+    for (int b = tau + 1; b < nbits; b++) if (allp || ((r >> b) & 1)) act |= 1u << b;
     act = __builtin_amdgcn_readfirstlane(act);
-    int64_t q0 = pos[c0], q1 = pos[c1];
+    const bool mine = lane < 32 && ((act >> lane) & 1);
+    const int32_t tv = mine ? opt[(int64_t)lane * n1 + prL] : 0;
+    int32_t acc = 0;
+    const int64_t q0 = pos[c0], q1 = pos[c1];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
     // (Tried: four 16-byte loads per lane and 1024 entries per iteration -- 101 VGPRs, occupancy 4, 18 % slower.)
-    for (int64_t qb = q0; qb < q1; qb += 256) {                // (a wave-uniform trip count keeps the counters on the scalar unit)
-        const int64_t q = qb + lane;                           // four independent coalesced loads in flight (eight: no faster)
-        int32_t v0 = q < q1 ? prev[q] : NEVER, v1 = q + 64 < q1 ? prev[q + 64] : NEVER, v2 = q + 128 < q1 ? prev[q + 128] : NEVER,
-                v3 = q + 192 < q1 ? prev[q + 192] : NEVER;
+    // eight coalesced loads per step, the next step's issued before this one's are counted: 4 KB in flight per wave
+    int32_t a[8], nx[8];
 #pragma unroll
-        for (int b = 0; b < NBMAX; b++) {
-            if (!((act >> b) & 1)) continue;                    // scalar branch: only the planes of this row
-            const int32_t t = thr[b];
-            cnt[b] += (int32_t)(ge ? (__popcll(__ballot(v0 >= t)) + __popcll(__ballot(v1 >= t)) + __popcll(__ballot(v2 >= t)) + __popcll(__ballot(v3 >= t)))
-                                   : (__popcll(__ballot(v0 < t)) + __popcll(__ballot(v1 < t)) + __popcll(__ballot(v2 < t)) + __popcll(__ballot(v3 < t))));
+    for (int k = 0; k < 8; k++) { const int64_t q = q0 + lane + 64 * k; a[k] = q < q1 ? prev[q] : NEVER; }
+    for (int64_t qb = q0; qb < q1; qb += 512) {                // (a wave-uniform trip count keeps the counters on the scalar unit)
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int64_t q = qb + 512 + lane + 64 * k; nx[k] = q < q1 ? prev[q] : NEVER; }
+        for (uint32_t rem = act; rem; rem &= rem - 1) {
+            const int b = __ffs(rem) - 1;
+            const int32_t t = __builtin_amdgcn_readlane(tv, b);
+            int32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) c += (int32_t)__popcll(__ballot(ge ? (a[k] >= t) : (a[k] < t)));
+            acc += lane == b ? c : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = nx[k];
+    }
+    int32_t outv = acc;
+    if (WPB > 1) {
+        __shared__ int32_t sacc[WPB > 1 ? WPB : 1][32];
+        const int wv = threadIdx.x >> 6;
+        if (lane < 32) sacc[wv][lane] = mine ? outv : 0;
+        __syncthreads();
+        if (wv != 0) return;
+        if (mine) {
+            int32_t t = 0;
+#pragma unroll
+            for (int k = 0; k < WPB; k++) t += sacc[k][lane];
+            outv = t;
         }
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < NBMAX; b++) {
-            if (!((act >> b) & 1)) continue;
-            if (chunks_per_row == 1) cr[(int64_t)b * n1 + PR(r)] = cnt[b];
-            else atomicAdd(&cr[(int64_t)b * n1 + PR(r)], cnt[b]);
-        }
+    if (mine) {
+        if (chunks_per_row == WPB) cr[(int64_t)lane * n1 + PR(r)] = outv;
+        else atomicAdd(&cr[(int64_t)lane * n1 + PR(r)], outv);
     }
 }
 
@@ -2106,7 +2167,7 @@ static void make_round(RoundDesc &R, bool isA, int tau, int nbits, int64_t n, in
 
 // right part of one round for one counter: rows with ctz == tau stream their 2^tau columns once for all bit planes
 static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n, int64_t rlo, int64_t rhi, const int64_t *cpos,
-                         const int32_t *link, int ge, const int32_t *opt, int32_t *cr)
+                         const int32_t *link, int ge, const int32_t *opt, int32_t *cr, double mean_deg)
 {
     const int allp = R.G.win;
     int tau = R.tau;
@@ -2119,15 +2180,27 @@ static void launch_rpass(hipStream_t s, const RoundDesc &R, int nbits, int64_t n
     int64_t nrows = u1 - u0;
     if (nrows <= 0) return;
     if (tau <= g_opt_rpass_small_tau) {
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<true>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr, allp);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<false>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, opt, cr, allp);
+        // lane-private share of a row: rpass_cap per cent of the mean number of entries of 2^tau columns, in steps of 16
+        int64_t cap = (int64_t)(0.01 * (double)g_opt_rpass_cap * mean_deg * (double)((int64_t)1 << tau));
+        cap = std::max<int64_t>(16, std::min<int64_t>((cap + 15) / 16 * 16, 1 << 20));
+#define RPS(GE, NB) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_small<GE, NB>), dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, s, tau, nbits, n, u0, nrows, cpos, link, \
+                                       opt, cr, allp, (int)cap)
+        // (up to 24 bit planes -- n < 2^24 -- the per-plane registers of the kernels are a quarter fewer: one more wave per SIMD)
+        if (nbits <= 24) { if (ge) RPS(true, 24); else RPS(false, 24); }
+        else             { if (ge) RPS(true, NBMAX); else RPS(false, NBMAX); }
+#undef RPS
     } else {
         int ch_cols = (int)g_opt_rpass_ch;          // columns per wave (cp_set_option("rpass_ch"))
         int64_t cpr = ((int64_t)1 << tau) > ch_cols ? (((int64_t)1 << tau) / ch_cols) : 1;
         if (cpr == 1) ch_cols = 1 << tau;
         int64_t waves = nrows * cpr;
-        if (ge) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<true>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr, allp);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<false>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, tau, nbits, n, u0, nrows, (int)cpr, ch_cols, cpos, link, opt, cr, allp);
+#define RPW(GE, WPB) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rpass_wave<GE, WPB>), dim3((unsigned)cdiv(waves, WPB)), dim3(64 * WPB), 0, s, tau, nbits, n, u0, \
+                                        nrows, (int)cpr, ch_cols, cpos, link, opt, cr, allp)
+        // the chunks of a row that share a workgroup add up in LDS before the row's counters see them
+        if (cpr % 16 == 0)     { if (ge) RPW(true, 16); else RPW(false, 16); }
+        else if (cpr % 4 == 0) { if (ge) RPW(true, 4);  else RPW(false, 4); }
+        else                   { if (ge) RPW(true, 1);  else RPW(false, 1); }
+#undef RPW
     }
 }
 
@@ -2272,8 +2345,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 hipLaunchKernelGGL(k_setup, dim3((unsigned)cdiv(R.ntask, 256)), dim3(256), 0, s, R, Wk.opt.p, Wk.nnopt.p, Wk.cr.p, 1,
                                    Wk.tdesc.p, A->pos32.p, Wk.tb.p, Wk.len.p, (const int32_t *)nullptr, hyp ? Wk.crl.p : (int32_t *)nullptr,
                                    (int32_t *)nullptr);
-            launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p);                   // prev[q] < B
-            if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p);      // rows ending in the column with first >= B
+            launch_rpass(s, R, nbits, n, rlo, rhi, A->pos.p, A->prev.p, 0, Wk.opt.p, Wk.cr.p, avg_deg);                   // prev[q] < B
+            if (hyp) launch_rpass(s, R, nbits, n, rlo, rhi, A->lpos.p, A->lfirst.p, 1, Wk.opt.p, Wk.crl.p, self_deg);      // rows ending in the column with first >= B
         }
         if (R.isA && R.nlast > 0) {
             CP_HIP(hipMemsetAsync(Wk.last_s0.p, 0, Wk.last_s0.bytes(), s));
