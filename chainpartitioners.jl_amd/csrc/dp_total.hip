@@ -476,6 +476,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     bool live;
     bool is_long = false, is_own = false, is_short = false;
     int64_t r = 0, B = 0, a = 0, S0 = 0, S0l = 0; int b = 0;
+    uint8_t finb = 0;
     if (R.isA) {
         int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         live = t < R.ntask;
@@ -494,7 +495,8 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             r = (base << (b + 1)) | ((int64_t)1 << b) | (((v << 1) | 1) << R.tau);
             }
             // (rows of a tau round have ctz == tau: their plane slot needs no bit search)
-            if (fin && fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))]) live = false;      // finished by a gap pass of an earlier round
+            // finished by a gap pass of an earlier round?  (the flag is looked at AFTER the gathers below are on their way: one memory latency less)
+            if (fin) finb = fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))];
         }
     }
     if (live && R.G.win) {
@@ -535,6 +537,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             if (a > B) a = B;          // cannot happen for an inverse-Monge cost; keeps every task well-formed
         }
     }
+    if (finb) live = false;
     if (live) {
         int64_t L = 1 + (B - a);
         if (dbg_ntriv && L > 1 && !R.isA) atomicAdd(dbg_ntriv, 1);
@@ -563,7 +566,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     __syncthreads();
     if (threadIdx.x == 0) {
         int32_t t0 = 0, t1 = 0; unsigned long long st = 0;
-        for (int w = 0; w < 16; w++) {
+        for (int w = 0, nw = (int)(blockDim.x >> 6); w < nw; w++) {
             int32_t c0 = s_wcnt[0][w], c1 = s_wcnt[1][w];
             s_wcnt[0][w] = t0; s_wcnt[1][w] = t1; t0 += c0; t1 += c1; st += s_wsteps[w];
         }
@@ -1735,15 +1738,32 @@ __global__ void __launch_bounds__(256) k_fix(const RoundCounts *__restrict__ rc,
 }
 
 // ------------------------------------------------------------------ combine the per-bit winners of every row
+// Which row a thread of the combine kernels takes.  lvl = 0: row rlo + i.  lvl = 1 (an experiment kept behind a debug option, see
+// run_layer): the row of plane slot i -- the order the planes are stored in (prow); row 0 is thread n.  Returns -1 for a thread
+// without a row.
+__device__ __forceinline__ int64_t combine_row(int64_t i, int64_t n, int64_t rlo, int64_t rhi, int lvl)
+{
+    int64_t r;
+    if (!lvl) r = rlo + i;
+    else if (i == n) r = 0;
+    else if (i > n) return -1;
+    else {
+        int t = 0;
+        while (t < 62 && n - (n >> (t + 1)) <= i) t++;             // level of slot i: base(t) <= i < base(t + 1), base(t) = n - (n >> t)
+        r = (((i - (n - (n >> t))) << 1) | 1) << t;
+    }
+    return (r < rlo || r > rhi) ? -1 : r;
+}
+
 template <typename TC>
-__global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t rhi, int nbits, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo, int64_t rhi, int nbits, const int64_t *__restrict__ pos,
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                  const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  TC *__restrict__ cst, int32_t *__restrict__ ptr)
 {
-    int64_t r = rlo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > rhi) return;
+    const int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
+    if (r < 0) return;
     int64_t n1 = n + 1;
     TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
     int64_t bp = r;
@@ -1762,14 +1782,14 @@ __global__ void __launch_bounds__(256) k_combine(int64_t n, int64_t rlo, int64_t
 // windowed layers: the candidates of row r from the right: the diagonal, the standard planes by ascending bit, the common plane,
 // the mirrored planes by descending bit -- strict < while moving left keeps the largest p on ties
 template <typename TC>
-__global__ void __launch_bounds__(256) k_combine_win(Geo G, int64_t n, int64_t rlo, int64_t rhi, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, int64_t rlo, int64_t rhi, const int64_t *__restrict__ pos,
                                                      const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                      const int32_t *__restrict__ nlopt,
                                                      const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                      TC *__restrict__ cst, int32_t *__restrict__ ptr)
 {
-    int64_t r = rlo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > rhi) return;
+    const int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
+    if (r < 0) return;
     const int64_t n1 = n + 1;
     TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
     int64_t bp = r;
@@ -2361,14 +2381,15 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
                 (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr, Wk.w_anch.p, Wk.w_anch2.p
-            dim3 sgrid((unsigned)cdiv(R.ntask, 1024));
+            const int sbs = (int)g_opt_setup_bs;          // lanes per block: one list atomic per block, but the block's waves meet at two barriers
+            dim3 sgrid((unsigned)cdiv(R.ntask, sbs));
             if (!R.isA) {                                // one grid row per bit plane above tau
                 int64_t mx = 1;
                 for (int bb = R.tau + 1; bb < nbits; bb++) mx = std::max<int64_t>(mx, R.tbase[bb + 1] - R.tbase[bb]);
-                sgrid = dim3((unsigned)cdiv(mx, 1024), (unsigned)std::max(1, nbits - R.tau - 1));
+                sgrid = dim3((unsigned)cdiv(mx, sbs), (unsigned)std::max(1, nbits - R.tau - 1));
             }
-            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), sgrid, dim3(1024), 0, s, SS_ARGS);
-            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), sgrid, dim3(1024), 0, s, SS_ARGS);
+            if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, true>), sgrid, dim3(sbs), 0, s, SS_ARGS);
+            else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_setup_short<TC, false>), sgrid, dim3(sbs), 0, s, SS_ARGS);
 #undef SS_ARGS
         }
         RoundCounts P;                                   // the counts this round is sized with
@@ -2568,11 +2589,16 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
         int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
+        // threads in row order.  (lvl = 1, cp_set_option("dbg", 16384): in plane-slot order, so that the dozen plane reads of a row are
+        // contiguous across a wave -- measured 867 us against 650 us at config 3: the 2 x 12 gathers W[p], pos[p] of a row are what
+        // counts, and they are neighbours only for neighbouring rows.)
+        const int lvl = (g_opt_dbg & 16384) ? (2 * (c1 - c0 + 1) >= n + 1) : 0;
+        const int64_t nthr = lvl ? n + 1 : c1 - c0 + 1;
         if (c1 >= c0 && G.win)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(c1 - c0 + 1, 256)), dim3(256), 0, s, G, n, c0, c1, A->pos.p,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, G, n, c0, c1, A->pos.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
         else if (c1 >= c0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(c1 - c0 + 1, 256)), dim3(256), 0, s, n, c0, c1, nbits, A->pos.p,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, n, c0, c1, nbits, A->pos.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
     CP_HIP(hipGetLastError());
