@@ -113,17 +113,17 @@ __device__ __forceinline__ bool bn_pred(const BnCtx<TC> &C, int64_t p, int64_t r
 // away from the hint -- two probes where the crossing did not move, 2 log2(distance) where it did -- instead of bisecting the
 // whole range; any hint is safe (it only chooses where the search starts).
 template <typename TC>
-__global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk, int phase,
+__global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk, int stride, int coarse,
                                                    int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0,
                                                    const int32_t *__restrict__ hint)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (phase == 0) t *= 64;
-    if (t >= nchunk || (phase == 1 && (t & 63) == 0)) return;
+    // chunks t = 0, stride, 2 stride, ...; coarse != 0: those that are multiples of `coarse` are known already and bracket the rest
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (t >= nchunk || (coarse && t % coarse == 0)) return;
     const int64_t r = rlo + t * CH;
     int64_t lo = 0, hi = r + 1;                             // the answer lies in [lo, hi]; pred is true at hi (r + 1: "no crossing")
-    if (phase == 1) {
-        const int64_t tl = t & ~(int64_t)63, tr = tl + 64;
+    if (coarse) {
+        const int64_t tl = t - t % coarse, tr = tl + coarse;
         lo = c0[tl];                                        // c(r) >= c(left coarse row)
         if (tr < nchunk && (int64_t)c0[tr] < hi) hi = c0[tr];      // c(r) <= c(right coarse row)
         if (lo > hi) lo = hi;
@@ -269,9 +269,11 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
     const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
     B->hint.ensure((size_t)nchunk);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 0, B->c0.p, B->nn0.p, B->nl0.p,
-                       hinted ? B->hint.p : (const int32_t *)nullptr);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, B->c0.p, B->nn0.p, B->nl0.p,
+    // every 64th chunk from the previous layer's hint, the rest bracketed by those.  (Tried: a level of every 8th chunk in between --
+    // 6 probes of the counter for most chunks instead of 9, but a third chain of dependent probes: 318 ms against 302.)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 64, 0, B->c0.p, B->nn0.p,
+                       B->nl0.p, hinted ? B->hint.p : (const int32_t *)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, 64, B->c0.p, B->nn0.p, B->nl0.p,
                        (const int32_t *)nullptr);
     CP_HIP(hipMemcpyAsync(B->hint.p, B->c0.p, sizeof(int32_t) * (size_t)nchunk, hipMemcpyDeviceToDevice, s));
     B->hint_nchunk = nchunk; B->hint_rlo = rlo; B->hint_ch = CH;
