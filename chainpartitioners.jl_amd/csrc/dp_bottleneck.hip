@@ -269,8 +269,14 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
     const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
     B->hint.ensure((size_t)nchunk);
-    // every 64th chunk from the previous layer's hint, the rest bracketed by those.  (Tried: a level of every 8th chunk in between --
-    // 6 probes of the counter for most chunks instead of 9, but a third chain of dependent probes: 318 ms against 302.)
+    // every 64th chunk from the previous layer's hint, the rest bracketed by those.  Tried, config 3 matrix, K = 64 (302 ms as is):
+    //  - a level of every 8th chunk in between: 6 probes of the counter for most chunks instead of 9, but a third chain of
+    //    dependent probes: 318 ms;
+    //  - the coarse starts by one WAVE per row, a 64-ary search over the whole range (4 rounds instead of ~25 dependent probes):
+    //    64 lanes x 24 levels x 5 loads of different cache lines per round keep the L1 busy for longer than the chain took
+    //    (1.58 ms per layer against 0.9 ms);
+    //  - the fine starts as a 4-ary search, three interleaved descents per step: 1.0 ms against 0.9 ms -- 1.25 M lanes are bound by
+    //    the number of line requests, not by the length of the chain.
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 64, 0, B->c0.p, B->nn0.p,
                        B->nl0.p, hinted ? B->hint.p : (const int32_t *)nullptr);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, 64, B->c0.p, B->nn0.p, B->nl0.p,
