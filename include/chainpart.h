@@ -212,7 +212,9 @@ int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
  * limit.  Layer driver of the O(K n log^2 n) scheme: "short_t"/"short_e" (tasks finished during setup),
  * "own_min" (shortest task with tiles of its own), "gap_tau"/"gap_min" (gap passes: rounds and task lengths; -1: none),
  * "ra_cache" (round A from counts cached per partition), "nospec" 1 (one host sync per round instead of sizing a layer from the
- * previous one), "rpass_ch"/"rpass_small_tau" (right-part passes), "prof_only" slot (events on one profile slot only), "dbg"
+ * previous one), "rpass_ch"/"rpass_small_tau"/"rpass_cap" (right-part passes: columns per wave, last
+ * lane-per-row round, lane-private share of a row in per cent of the mean), "setup_bs" (lanes per block of the task setup), "bn_chunk"
+ * (rows per walk of the bottleneck DP), "prof_only" slot (events on one profile slot only), "dbg"
  * (diagnostic bit mask).  Unknown names return CP_EINVAL. */
 int32_t cp_set_option(const char *name, int64_t value);
 /* built-in per-kernel HIP-event timing of the named hot kernels on the launch stream */
