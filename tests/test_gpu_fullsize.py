@@ -164,3 +164,48 @@ def test_config3_shape_constrained_and_bottleneck_dps(hip):
         assert v1 == vi and len(set(b1.tolist())) > K // 2
     finally:
         hip.csr_destroy(h)
+
+
+def test_one_handle_through_many_dps_equals_fresh_handles(hip):
+    """State kept on a matrix handle between calls (layer work buffers, the previous layer's task counts that size the next
+    one, window anchors, counters, walk hints) must never change a result: every call of a shuffled sequence of DPs -- other
+    models, part counts, widths, loop orders, objectives -- on ONE handle equals the same call on a fresh handle."""
+    from bench import gen_suitesparse_shaped
+    n, N = 2_000_000, 20_000_000
+    dev = torch.device("cuda", 0)
+    colptr, rowval = gen_suitesparse_shaped(n, N, 0xDEADBEEF + 9, dev)
+    net1 = cp.AffineConnectivityModel(0, 0, 0, 1).marshal()
+    net2 = cp.AffineConnectivityModel(0, 10, 1, 100).marshal()
+    hyp = cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3).marshal()
+    hypb = cp.AffineHyperedgeCutModel(0, 2, 1, 3, 1).marshal()          # (the bottleneck valley needs beta_self >= beta_cut)
+    fnet = cp.AffineConnectivityModel(0.0, 3.0, 1.0, 7.0).marshal()
+    wm = cp.VertexCount().marshal()
+
+    def w_of(K, num, den):
+        return -(-num * n // (den * K))
+    calls = [("sum", net1, 6, 0, w_of(6, 3, 2)), ("sum", net1, 24, 0, w_of(24, 3, 2)), ("sum", net1, 5, 0, 0), ("max", net2, 12, 0, 0),
+             ("sum", hyp, 6, 0, w_of(6, 3, 2)), ("sum", net1, 6, 1, w_of(6, 3, 2)), ("sum", fnet, 9, 0, w_of(9, 5, 4)), ("max", hypb, 7, 0, 0),
+             ("sum", net2, 3, 0, 0), ("sum", net1, 6, 0, w_of(6, 11, 10)), ("max", fnet, 20, 0, 0), ("sum", hyp, 4, 0, 0)]
+
+    def run(h, c):
+        kind, mm, K, order, w = c
+        spl = np.zeros(K + 1, dtype=np.int64)
+        rc = hip.partition_dynamic(h, K, 1 if kind == "max" else 0, order, mm, None, wm if w else None, w, float(w), spl)
+        assert rc == 0, (c[0], K, order, w, hip.last_error())
+        return spl
+    fresh = []
+    for c in calls:
+        h = _handle(hip, n, colptr, rowval)
+        try:
+            fresh.append(run(h, c))
+        finally:
+            hip.csr_destroy(h)
+    assert sum(len(set(s.tolist())) > 3 for s in fresh) >= 6          # (the constrained and bottleneck answers are not degenerate)
+    rng = np.random.default_rng(5)
+    h = _handle(hip, n, colptr, rowval)
+    try:
+        for rep in range(3):
+            for i in rng.permutation(len(calls)):
+                assert np.array_equal(run(h, calls[i]), fresh[i]), (rep, i, calls[i][0], calls[i][2:])
+    finally:
+        hip.csr_destroy(h)
