@@ -43,18 +43,18 @@ def test_bottleneck_tables_bit_exact(hip, orc, mi):
 
 
 def test_chunk_sizes_and_general_sweep_agree(hip, orc):
-    A = suitesparse_shaped(3000, 8, 11)
-    for mdl in (MODELS[1], MODELS[4], MODELS[6]):
+    for A in (suitesparse_shaped(3000, 8, 11), suitesparse_shaped(3000, 30, 5)):
+      for mdl in (MODELS[1], MODELS[4], MODELS[6]):
         K = 6
         mm = mdl.marshal()
         rc2, p2, c2 = orc.dynamic_tables(A, K, 1, mm, None)
-        for ch in (1, 7, 128, 100000):
-            hip.set_option("bn_chunk", ch)
+        for ch, dbg in ((1, 0), (3, 0), (7, 0), (16, 0), (128, 0), (100000, 0)):
+            hip.set_option("bn_chunk", ch); hip.set_option("dbg", dbg)
             try:
                 rc1, p1, c1 = hip.dynamic_tables(A, K, 1, mm, None)
             finally:
-                hip.set_option("bn_chunk", 8)
-            assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ch
+                hip.set_option("bn_chunk", 8); hip.set_option("dbg", 0)
+            assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), (ch, dbg)
         hip.set_option("force_brute", 1)
         try:
             rc1, p1, c1 = hip.dynamic_tables(A, K, 1, mm, None)
