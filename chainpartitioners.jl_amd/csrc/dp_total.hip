@@ -1271,13 +1271,23 @@ __global__ void __launch_bounds__(256) k_gap_merge(int tau, int nchunk, const Ro
         const int64_t rwL = (int64_t)b * n1 + PR((int64_t)g.rL);
         const int32_t anchor = nnopt[rwL], anchor2 = HYP ? nlopt[rwL] : 0;
         TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
-        for (int sg = 0; sg < nseg; sg++) {
-            const GapSegRec<TC, HYP> rec = gseg[((int64_t)(le.y + sg) * nchunk + ck) * 64 + lane];
-            if (rec.p >= 0) {
-                TC v = cadd(rec.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)cum, (int64_t)cum2));
-                if (bp < 0 || v < bv) { bv = v; bp = rec.p; bl = rec.l + cum; bl2 = rec.l2 + cum2; }
+        // (the task over the top rectangle's whole block has thousands of segments: eight records per lane in flight -- the running
+        //  counts make the merge sequential, the loads need not be)
+        for (int s0 = 0; s0 < nseg; s0 += 8) {
+            GapSegRec<TC, HYP> rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (s0 + u < nseg) rr[u] = gseg[((int64_t)(le.y + s0 + u) * nchunk + ck) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (s0 + u >= nseg) break;
+                const GapSegRec<TC, HYP> rec = rr[u];
+                if (rec.p >= 0) {
+                    TC v = cadd(rec.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)cum, (int64_t)cum2));
+                    if (bp < 0 || v < bv) { bv = v; bp = rec.p; bl = rec.l + cum; bl2 = rec.l2 + cum2; }
+                }
+                cum += rec.cum; cum2 += rec.cum2;
             }
-            cum += rec.cum; cum2 += rec.cum2;
         }
         if (g.valid) {
             int64_t rw = (int64_t)b * n1 + PR((int64_t)g.rr);
@@ -1358,17 +1368,30 @@ __global__ void __launch_bounds__(256) k_fix_own(const RoundCounts *__restrict__
     int4 td = tdesc[t];
     int64_t S0 = td.y, S0l = HYP ? (int64_t)tS0l[t] : 0;
     Best<TC, HYP> acc; best_clear(acc);
-    for (int64_t k = k0 + (WPT == 1 ? lane : (int64_t)threadIdx.x); k < k1; k += 64 * WPT) {
-        Best<TC, HYP> c = part[k];
-        if (c.p >= 0) {
-            int64_t base = S0 + (tilePS[k] - tilePS[k0]);
-            int64_t base2 = HYP ? S0l + (tilePS2[k] - tilePS2[k0]) : 0;
-            c.v = cadd(c.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, base, base2));
-            c.nn = (int32_t)(c.nn + base);
-            if (HYP) best_set_nl(c, (int32_t)(best_nl(c) + base2));
+    // (In every round the last row of the top rectangle owns a task over its whole block -- tens of thousands of tiles: eight tiles
+    //  per lane and step are in flight; one at a time, that task alone took 30 us of every round.)
+    const int64_t ps0 = tilePS[k0], ps20 = HYP ? tilePS2[k0] : 0;
+    for (int64_t kb = k0 + (WPT == 1 ? lane : (int64_t)threadIdx.x); kb < k1; kb += 8 * 64 * WPT) {
+        Best<TC, HYP> cc[8]; int64_t ps[8], ps2[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t k = kb + (int64_t)u * 64 * WPT;
+            best_clear(cc[u]); ps[u] = 0; ps2[u] = 0;
+            if (k < k1) { cc[u] = part[k]; ps[u] = tilePS[k]; if (HYP) ps2[u] = tilePS2[k]; }
         }
-        bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
-        if (take) acc = c;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            Best<TC, HYP> c = cc[u];
+            if (c.p >= 0) {
+                int64_t base = S0 + (ps[u] - ps0);
+                int64_t base2 = HYP ? S0l + (ps2[u] - ps20) : 0;
+                c.v = cadd(c.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, base, base2));
+                c.nn = (int32_t)(c.nn + base);
+                if (HYP) best_set_nl(c, (int32_t)(best_nl(c) + base2));
+            }
+            bool take = (acc.p < 0) ? (c.p >= 0) : (c.p >= 0 && (c.v < acc.v || (c.v == acc.v && c.p > acc.p)));
+            if (take) acc = c;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         int src = (lane + o) & 63;
@@ -2011,7 +2034,15 @@ __global__ void __launch_bounds__(256) k_ra_merge(RATab T, int64_t nrow, const B
     const int64_t u = w - T.rbase[b], r = ((u << 1) | 1) << b, n1 = T.n + 1;
     const int64_t t0 = T.tbase[b] + (u << (b - 8)) - T.tbase[9], cntt = (int64_t)1 << (b - 8);
     Best<TC, HYP> x; best_clear(x);
-    for (int64_t k = lane; k < cntt; k += 64) { Best<TC, HYP> c = part[t0 + k]; if (ra_takes(x, c)) x = c; }
+    // (the top row's block is half the matrix -- 2^15 partials at n = 10^7: eight loads per lane in flight; one at a time, that row
+    //  alone made the kernel 160 us long)
+    for (int64_t kb = lane; kb < cntt; kb += 512) {
+        Best<TC, HYP> cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { best_clear(cc[u]); if (kb + 64 * u < cntt) cc[u] = part[t0 + kb + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (kb + 64 * u < cntt && ra_takes(x, cc[u])) x = cc[u];
+    }
     for (int o = 32; o > 0; o >>= 1) {
         Best<TC, HYP> c; best_clear(c);
         c.v = shfl64(x.v, lane ^ o); c.p = __shfl(x.p, lane ^ o); c.nn = __shfl(x.nn, lane ^ o);
