@@ -771,13 +771,19 @@ __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr,
             int32_t pb = xc + 4 * lane;
             // entries at or above Q_hi belong to columns above the tile: never flagged (those below Q_lo lie below every s)
             // the lane's four flags, and the four wave masks
-            const bool f0 = pb < Q_hi && (GE ? v.x >= thr : v.x < thr), f1 = pb + 1 < Q_hi && (GE ? v.y >= thr : v.y < thr);
-            const bool f2 = pb + 2 < Q_hi && (GE ? v.z >= thr : v.z < thr), f3 = pb + 3 < Q_hi && (GE ? v.w >= thr : v.w < thr);
+            // (a block that lies inside the run -- all but the first and the last one -- needs none of the position guards: wave-uniform)
+            const bool inner = xc >= Q_lo && xc + 256 <= Q_hi;
+            bool f0 = GE ? v.x >= thr : v.x < thr, f1 = GE ? v.y >= thr : v.y < thr, f2 = GE ? v.z >= thr : v.z < thr, f3 = GE ? v.w >= thr : v.w < thr;
+            if (!inner) { f0 = f0 && pb < Q_hi; f1 = f1 && pb + 1 < Q_hi; f2 = f2 && pb + 2 < Q_hi; f3 = f3 && pb + 3 < Q_hi; }
             const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
             if (DET) {
                 const uint32_t span = (uint32_t)(sp_hi - sp_lo - 1);           // v in (sp_lo, sp_hi)  <=>  (uint)(v - sp_lo - 1) < span
-                bool s0 = pb >= Q_lo && pb < Q_hi && (uint32_t)(v.x - sp_lo - 1) < span, s1 = pb + 1 >= Q_lo && pb + 1 < Q_hi && (uint32_t)(v.y - sp_lo - 1) < span;
-                bool s2 = pb + 2 >= Q_lo && pb + 2 < Q_hi && (uint32_t)(v.z - sp_lo - 1) < span, s3 = pb + 3 >= Q_lo && pb + 3 < Q_hi && (uint32_t)(v.w - sp_lo - 1) < span;
+                bool s0 = (uint32_t)(v.x - sp_lo - 1) < span, s1 = (uint32_t)(v.y - sp_lo - 1) < span, s2 = (uint32_t)(v.z - sp_lo - 1) < span,
+                     s3 = (uint32_t)(v.w - sp_lo - 1) < span;
+                if (!inner) {
+                    s0 = s0 && pb >= Q_lo && pb < Q_hi; s1 = s1 && pb + 1 >= Q_lo && pb + 1 < Q_hi;
+                    s2 = s2 && pb + 2 >= Q_lo && pb + 2 < Q_hi; s3 = s3 && pb + 3 >= Q_lo && pb + 3 < Q_hi;
+                }
                 if (s0 || s1 || s2 || s3) {                           // rare; only the lanes holding a special work here
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
