@@ -144,6 +144,9 @@ __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64
 // over the rows bucketed by their LAST column).
 // The 64 rows of a wave are consecutive, so they share every bit above tau + 6: planes whose bit is clear in the whole
 // wave are skipped with a wave-uniform test (about half of them).
+// (Tried: G = 2 .. 16 lanes per row, the group reading 16 G contiguous entries per step (a load instruction within 8 cache lines
+//  instead of 64) and adding up by a butterfly: 238 / 262 / 288 / 325 us at tau = 4 .. 1 against 161 / 149 / 167 / 217 -- the
+//  per-wave prelude (thresholds of two dozen planes) is then paid per 64 / G rows.)
 // (Tried: deciding all planes but one by the position of the link value among the Fenwick blocks, with lane-private LDS
 //  histograms -- 4x fewer VALU instructions but 300 B of LDS per row leave 2 waves per SIMD: slower.)
 template <bool ge, int NB>
