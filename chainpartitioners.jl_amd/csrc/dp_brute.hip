@@ -17,7 +17,7 @@
 namespace cpk {
 
 int64_t g_opt_force_brute = 0;
-int64_t g_opt_short_t = 4, g_opt_short_e = 64;
+int64_t g_opt_short_t = 8, g_opt_short_e = 64;
 int64_t g_opt_own_min = 64;
 int64_t g_opt_rpass_ch = 256;
 int64_t g_opt_rpass_small_tau = 4;

@@ -602,22 +602,34 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         if (L == 1 && !R.isA) {                  // one candidate: nothing to compare
             opt[rw] = (int32_t)B; nnopt[rw] = (int32_t)S0; if (HYP) nlopt[rw] = (int32_t)S0l;
         } else {
-            int32_t rr = (int32_t)r, posr = pos32[r];
+            // The walk is a chain of dependent loads (the kernel spends 2/3 of its wave cycles waiting on memory): the column pointer and
+            // the previous-layer cost of the NEXT candidate are requested before the current column is stepped over, and a column's
+            // entries go eight at a time -- one memory latency per candidate instead of four or five.
+            const int32_t rr = (int32_t)r, posr = pos32[r];
             int64_t nn = S0, nl = S0l;
             Best<TC, HYP> best; best_clear(best);
+            int32_t pp = pos32[B], pq = 0, fp = HYP ? fpos32[B] : 0, fq = 0;      // colptr of the candidate (pp, fp) and of the column after it (pq, fq)
+            TC wp = W[B];
             for (int64_t i = 0; i < L; i++) {    // decreasing p: an earlier candidate wins ties
-                int64_t p = B - i;
-                if (i > 0) {
-                    for (int32_t q = pos32[p], q1 = pos32[p + 1]; q < q1; q += 4) {      // four loads in flight
-                        int32_t v0 = next[q], v1 = q + 1 < q1 ? next[q + 1] : -1, v2 = q + 2 < q1 ? next[q + 2] : -1, v3 = q + 3 < q1 ? next[q + 3] : -1;
-                        nn += (v0 >= rr) + (v1 >= rr) + (v2 >= rr) + (v3 >= rr);
+                const int64_t p = B - i;
+                int32_t pn = 0, fn = 0; TC wn = (TC)0;
+                if (i + 1 < L) { pn = pos32[p - 1]; wn = W[p - 1]; if (HYP) fn = fpos32[p - 1]; }
+                if (i > 0) {                     // step over column p: its entries are [pp, pq)
+                    for (int32_t q = pp; q < pq; q += 8) {
+                        int32_t v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) v[k] = q + k < pq ? next[q + k] : -1;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) nn += (v[k] >= rr);
                     }
-                    if (HYP) for (int32_t q = fpos32[p]; q < fpos32[p + 1]; q++) nl += (flast[q] < rr);
+                    if (HYP) for (int32_t q = fp; q < fq; q++) nl += (flast[q] < rr);
                 }
-                if (i == 0 && R.isA) continue;   // round A: p = r is not a candidate
-                TC fv = dm_apply(M, alpha, r - p, (int64_t)(posr - pos32[p]), nn, nl);
-                Best<TC, HYP> c; best_clear(c); c.v = cadd(W[p], fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
-                best = better(best, c);
+                if (!(i == 0 && R.isA)) {        // (round A: p = r is not a candidate)
+                    TC fv = dm_apply(M, alpha, r - p, (int64_t)(posr - pp), nn, nl);
+                    Best<TC, HYP> c; best_clear(c); c.v = cadd(wp, fv); c.p = (int32_t)p; c.nn = (int32_t)nn; best_set_nl(c, (int32_t)nl);
+                    best = better(best, c);
+                }
+                pq = pp; pp = pn; wp = wn; fq = fp; fp = fn;
             }
             opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
         }

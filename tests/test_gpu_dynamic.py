@@ -128,7 +128,7 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
                 try:
                     rc1, p1, c1 = hip.dynamic_tables(M_, 5, 0, mm, None)
                 finally:
-                    hip.set_option("short_t", 4); hip.set_option("short_e", 64); hip.set_option("own_min", 64)
+                    hip.set_option("short_t", 8); hip.set_option("short_e", 64); hip.set_option("own_min", 64)
                 assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), ("short", st, om, M_)
 
 
