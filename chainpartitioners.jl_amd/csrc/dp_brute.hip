@@ -24,7 +24,7 @@ int64_t g_opt_rpass_small_tau = 4;
 int64_t g_opt_setup_bs = 1024;          // lanes per block of k_setup_short (a multiple of 64, at most 1024)
 int64_t g_opt_rpass_cap = 200;          // lane-private entries per row in k_rpass_small, per cent of the mean
 int64_t g_opt_nospec = 0, g_spec_redo = 0;
-int64_t g_opt_gap_tau = 5, g_opt_gap_min = 64;
+int64_t g_opt_gap_tau = 6, g_opt_gap_min = 64;
 int64_t g_opt_ra_cache = 1;
 int64_t g_opt_fixed_point = 0;
 int64_t g_opt_brute_max_n = 200000;

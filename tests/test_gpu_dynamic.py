@@ -146,7 +146,7 @@ LAYER_OPTIONS = [{"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 0}, {"gap_tau": 3, 
                  {"dbg": 1024}, {"dbg": 2048}, {"dbg": 1024 + 2048, "gap_tau": -1},
                  # layers after one that reproduced its input row are copied (exact; off by default)
                  {"fixed_point": 1}]
-LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 5, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "setup_bs": 1024, "fixed_point": 0}
+LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 6, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "setup_bs": 1024, "fixed_point": 0}
 
 
 @pytest.mark.parametrize("oi", range(len(LAYER_OPTIONS)))

@@ -144,7 +144,7 @@ def test_config3_shape_constrained_and_bottleneck_dps(hip):
                 spl2 = np.zeros(K + 1, dtype=np.int64)
                 assert hip.partition_dynamic(h, K, 0, 0, mm, None, wm, w, float(w), spl2) == 0, (opts, hip.last_error())
             finally:
-                hip.set_option("nospec", 0); hip.set_option("gap_tau", 5)
+                hip.set_option("nospec", 0); hip.set_option("gap_tau", 6)
             assert np.array_equal(spl, spl2), opts
         # the chunker loop order fills the same tables
         spl3 = np.zeros(K + 1, dtype=np.int64)

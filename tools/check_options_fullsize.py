@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 hip = _lib.HipBackend(device=0)
 colptr, rowval = gen_suitesparse_shaped(n, 10 * n, 0xDEADBEEF + 2, dev)
 h = hip.csr_from_device(n, n, int(rowval.numel()), colptr.data_ptr(), rowval.data_ptr())
-defaults = {"nospec": 0, "gap_tau": 5, "ra_cache": 1, "fixed_point": 0}
+defaults = {"nospec": 0, "gap_tau": 6, "ra_cache": 1, "fixed_point": 0}
 bad = 0
 for mdl in (cp.AffineConnectivityModel(20000, 10, 1, 100), cp.AffineHyperedgeCutModel(3000, 0, 0, 1, 3)):
     mm = mdl.marshal()
