@@ -1800,7 +1800,7 @@ __device__ __forceinline__ int64_t combine_row(int64_t i, int64_t n, int64_t rlo
 }
 
 template <typename TC>
-__global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo, int64_t rhi, int nbits, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo, int64_t rhi, int nbits, const int32_t *__restrict__ pos,
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                  const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
@@ -1816,7 +1816,7 @@ __global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo
         int64_t p = opt[(int64_t)b * n1 + PR(r)];
         int64_t nn = nnopt[(int64_t)b * n1 + PR(r)];
         int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + PR(r)] : 0;
-        TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, nl));
+        TC v = cadd(W[p], dm_apply(M, alpha, r - p, (int64_t)(pos[r] - pos[p]), nn, nl));
         if (v < bv) { bv = v; bp = p; }            // lower bits hold larger p: strict < keeps the largest p on ties
     }
     cst[r] = bv;
@@ -1826,7 +1826,7 @@ __global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo
 // windowed layers: the candidates of row r from the right: the diagonal, the standard planes by ascending bit, the common plane,
 // the mirrored planes by descending bit -- strict < while moving left keeps the largest p on ties
 template <typename TC>
-__global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, int64_t rlo, int64_t rhi, const int64_t *__restrict__ pos,
+__global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, int64_t rlo, int64_t rhi, const int32_t *__restrict__ pos,
                                                      const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                      const int32_t *__restrict__ nlopt,
                                                      const TC *__restrict__ W, DevModel<TC> M, TC alpha,
@@ -1848,7 +1848,7 @@ __global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, 
             const int64_t p = opt[(int64_t)b * n1 + slot];
             const int64_t nn = nnopt[(int64_t)b * n1 + slot];
             const int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + slot] : 0;
-            const TC v = cadd(W[p], dm_apply(M, alpha, r - p, pos[r] - pos[p], nn, nl));
+            const TC v = cadd(W[p], dm_apply(M, alpha, r - p, (int64_t)(pos[r] - pos[p]), nn, nl));
             if (v < bv) { bv = v; bp = p; }
         }
     }
@@ -2647,10 +2647,10 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         const int lvl = (g_opt_dbg & 16384) ? (2 * (c1 - c0 + 1) >= n + 1) : 0;
         const int64_t nthr = lvl ? n + 1 : c1 - c0 + 1;
         if (c1 >= c0 && G.win)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, G, n, c0, c1, A->pos.p,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, G, n, c0, c1, A->pos32.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
         else if (c1 >= c0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, n, c0, c1, nbits, A->pos.p,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, n, c0, c1, nbits, A->pos32.p,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
     }
     CP_HIP(hipGetLastError());
