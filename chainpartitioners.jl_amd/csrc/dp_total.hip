@@ -2042,6 +2042,95 @@ __global__ void __launch_bounds__(256) k_ra_layer(RATab T, int64_t ntile, const 
     }
 }
 
+// The same round, COLUMN-major: one wave per 256 consecutive candidates p, all levels.  A candidate p belongs to the round-A row
+// of every level b whose bit is clear in p (r = p with the bits below b cleared, plus 2^b), a dozen rows on average: k_ra_layer reads
+// its cost W[p] and its column pointer once per row (16 B per (candidate, row)); here they are read once per candidate and
+// only the 4-byte cached count is read per row -- 60 B instead of 190 B per candidate and layer.  Lane l holds the candidates
+// P0 + 4 l .. + 3; the count elements of a row are stored by descending p (ra_decode), so a lane's four are one aligned vector.
+// Rows of up to 256 candidates (b <= 8) lie inside the wave's columns and are finished here (butterfly over the row's lanes);
+// longer rows leave one partial per 256 candidates for k_ra_merge, in the slot k_ra_layer would use.
+template <typename TC, bool HYP>
+__global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restrict__ cnt, const int32_t *__restrict__ cnt2,
+                                                 const int32_t *__restrict__ pos, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
+                                                 int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
+                                                 Best<TC, HYP> *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = T.n, n1 = n + 1;
+    const int64_t P0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LT;
+    if (P0 >= n) return;                                    // (wave-uniform) candidates are the columns 0 .. n - 1
+    const int64_t p0 = P0 + 4 * lane;
+    TC wv[4]; int32_t pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int64_t p = p0 + k < n ? p0 + k : n; wv[k] = W[p]; pv[k] = pos[p]; }
+    for (int b = 0; b < T.nbits; b++) {
+        if (b >= 8 && ((P0 >> b) & 1)) continue;            // (wave-uniform) the wave's columns have the bit set: no row of this level
+        // the lane's row of this level and its candidates among p0 .. p0 + 3
+        //   b = 0: two rows of one candidate (p0 -> p0 + 1, p0 + 2 -> p0 + 3); b = 1: the row p0 + 2 with p0, p0 + 1;  b >= 2: all four
+        const bool cov = b < 2 || !((p0 >> b) & 1);
+        const int64_t r = b == 0 ? p0 + 1 : ((p0 >> (b + 1)) << (b + 1)) + ((int64_t)1 << b);
+        const int64_t u = p0 >> (b + 1), mask = ((int64_t)1 << b) - 1;
+        // element of the lane's LAST candidate of the row (the smallest element index: elements run by descending p)
+        const int64_t plast = b == 0 ? p0 : b == 1 ? p0 + 1 : p0 + 3;
+        const int64_t e = (u << b) | (mask - (plast & mask));
+        const int64_t E = (T.tbase[b] << 8) + e;
+        int32_t c[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+        if (cov) {
+            if (b >= 2) {
+                const int4 t = *reinterpret_cast<const int4 *>(cnt + E);
+                c[3] = t.x; c[2] = t.y; c[1] = t.z; c[0] = t.w;
+                if (HYP) { const int4 t2 = *reinterpret_cast<const int4 *>(cnt2 + E); d[3] = t2.x; d[2] = t2.y; d[1] = t2.z; d[0] = t2.w; }
+            } else if (b == 1) {
+                const int2 t = *reinterpret_cast<const int2 *>(cnt + E);
+                c[1] = t.x; c[0] = t.y;
+                if (HYP) { const int2 t2 = *reinterpret_cast<const int2 *>(cnt2 + E); d[1] = t2.x; d[0] = t2.y; }
+            } else {                                        // b = 0: elements of p0 and p0 + 2 are neighbours
+                const int2 t = *reinterpret_cast<const int2 *>(cnt + E);
+                c[0] = t.x; c[2] = t.y;
+                if (HYP) { const int2 t2 = *reinterpret_cast<const int2 *>(cnt2 + E); d[0] = t2.x; d[2] = t2.y; }
+            }
+        }
+        if (b == 0) {                                       // single candidates: nothing to compare
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                const int64_t rk = p0 + k + 1;
+                if (rk <= n) { const int64_t rw = PR(rk); opt[rw] = (int32_t)(p0 + k); nnopt[rw] = c[k]; if (HYP) nlopt[rw] = d[k]; }
+            }
+            continue;
+        }
+        const bool rok = cov && r <= n;
+        const int32_t posr = pos[rok ? r : 0];
+        Best<TC, HYP> x; best_clear(x);
+        const int nk = b == 1 ? 2 : 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= nk || !rok) continue;
+            Best<TC, HYP> cc; best_clear(cc);
+            cc.v = cadd(wv[k], dm_apply(M, alpha, r - (p0 + k), (int64_t)(posr - pv[k]), (int64_t)c[k], (int64_t)d[k]));
+            cc.p = (int32_t)(p0 + k); cc.nn = c[k]; best_set_nl(cc, d[k]);
+            if (ra_takes(x, cc)) x = cc;
+        }
+        const int lpr = b <= 2 ? 1 : b >= 8 ? 64 : (1 << (b - 2));          // lanes per row
+        for (int o = 1; o < lpr; o <<= 1) {                 // butterfly inside the row's lanes: every lane ends with the winner
+            Best<TC, HYP> cc; best_clear(cc);
+            cc.v = shfl64(x.v, lane ^ o); cc.p = __shfl(x.p, lane ^ o); cc.nn = __shfl(x.nn, lane ^ o);
+            if (HYP) best_set_nl(cc, __shfl(best_nl(x), lane ^ o));
+            if (ra_takes(x, cc)) x = cc;
+        }
+        if ((lane & (lpr - 1)) == 0 && rok) {
+            if (b <= 8) {
+                const int64_t rw = (int64_t)b * n1 + PR(r);
+                opt[rw] = x.p; nnopt[rw] = x.nn;
+                if (HYP) nlopt[rw] = best_nl(x);
+            } else {
+                // lane 0: the wave's smallest element of the row is that of its last column (P0 + 255)
+                const int64_t el = (u << b) | (mask - ((P0 + LT - 1) & mask));
+                part[T.tbase[b] + (el >> 8) - T.tbase[9]] = x;
+            }
+        }
+    }
+}
+
 // rows of more than LT candidates (b >= 9): one wave per row merges the row's tile partials
 template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_ra_merge(RATab T, int64_t nrow, const Best<TC, HYP> *__restrict__ part,
@@ -2391,13 +2480,23 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             // last row in its upper planes
             if (!Wk.ra_built) { ProfScope ps(PROF_LINKS, s, 0.0); ra_build<TC>(A, Wk); }
             ProfScope ps(PROF_RA, s, 16.0 * (double)Wk.ra_ntile * LT);
+            const bool colmajor = !(g_opt_dbg & 262144);       // (dbg 262144: the row-major kernel k_ra_layer)
+            const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
+            if (colmajor && hyp)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
+            else if (colmajor)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p));
             if (hyp) {
+                if (!colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p, Wk.ra_c2.p,
                                    A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
                 if (Wk.ra_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(Wk.ra_nrow, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_nrow,
                                                        Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
             } else {
                 auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
+                if (!colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, false>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p,
                                    (const int32_t *)nullptr, A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa);
                 if (Wk.ra_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(Wk.ra_nrow, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_nrow,
