@@ -759,6 +759,9 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // appended to the wave's list by the lanes that hold them (LDS counter s_cnt): s_es[i] = the entry's position (the caller turns it
 // into the first step whose candidate has the entry's column on its right), s_v[i] = the value, tagged with `kind` in bit 31.
 // Only the first SMAX specials are stored; s_cnt keeps counting.
+// (Tried: the link values in 3 bytes (n < 2^24), a 12-byte load and six vector instructions to unpack four entries -- 19 % fewer
+//  bytes per step, and k_lpass_own 9 % SLOWER (254 vs 232 ms per partition): at 0.8 of the HBM roofline the kernel has no vector
+//  issue slots to spare.)
 constexpr int SMAX = 31;
 template <bool GE, bool DET = false>
 __device__ __forceinline__ void interior_stream(const int32_t *__restrict__ arr, const int32_t *__restrict__ cpos, int32_t p_first, int32_t tl,
