@@ -759,6 +759,9 @@ __device__ __forceinline__ int32_t coop_count(const int32_t *__restrict__ arr, i
 // appended to the wave's list by the lanes that hold them (LDS counter s_cnt): s_es[i] = the entry's position (the caller turns it
 // into the first step whose candidate has the entry's column on its right), s_v[i] = the value, tagged with `kind` in bit 31.
 // Only the first SMAX specials are stored; s_cnt keeps counting.
+// (Tried: a step's count taken once, in the block its column starts in, as TOTAL - (flagged entries below the start), the groups
+//  that can start in a block picked on the scalar side -- 30 instead of 70 vector instructions per block, but 65 VGPRs: 254 ms
+//  against 232; forced back to 64 VGPRs: 241 ms.)
 // (Tried: the link values in 3 bytes (n < 2^24), a 12-byte load and six vector instructions to unpack four entries -- 19 % fewer
 //  bytes per step, and k_lpass_own 9 % SLOWER (254 vs 232 ms per partition): at 0.8 of the HBM roofline the kernel has no vector
 //  issue slots to spare.)
