@@ -2221,6 +2221,10 @@ struct LayerWork {
     DBuf<RoundCounts> rc;                               // per-round counters of the current layer (device)
     std::vector<RoundCounts> pred;                      // ... of the previous layer (host): sizes the next one
     bool pred_ok = false; int64_t pred_rlo = 0, pred_rhi = 0; double pred_scale = 1.0; int pred_win = 0; int64_t pred_w = 0;
+    // rounds whose flattened stage served a handful of tasks in the last layer that ran it: their medium tasks get tiles of their
+    // own from then on and the stage (six dependent launches, ~40 us) is skipped -- see run_layer
+    std::vector<uint8_t> force_own;
+    int64_t force_rows = 0;               // rows of the layer the flags come from (a one-row last layer says nothing about a full one)
     // (o_rec / loc are the size witnesses of their groups: they are released first and allocated LAST, so a hipMalloc failure in
     //  the middle leaves the witness empty and the next call allocates the whole group again)
     void ensure_own(size_t NT) {                        // per-tile arrays of the own-tiled tasks
@@ -2451,7 +2455,7 @@ constexpr int64_t LB_MAX = 1 << 20;      // largest scan (elements) done in a si
 // the exact counts back before the dependent launches (the only mode of the first layer).
 template <typename TC>
 static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out, LayerWork<TC> &Wk,
-                      int64_t rlo, int64_t rhi, bool spec)
+                      int64_t rlo, int64_t rhi, bool spec, bool allow_force = true)
 {
     hipStream_t s = A->stream;
     const int64_t n = A->n;
@@ -2476,6 +2480,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     std::vector<Patch> patches;                          // profile records whose algorithmic bytes depend on the true counts
     auto note = [&](int rd, int kind, int slot) { if (prof_active(slot)) patches.push_back({g_prof_pending.size() - 1, rd, kind}); };
     auto grow = [](int64_t v) { return v + (v >> 2) + 1024; };     // head room over the prediction
+    bool any_forced = false;
 
     for (int rd = 0; rd <= nbits; rd++) {
         RoundDesc R;
@@ -2515,6 +2520,12 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         CP_REQUIRE(R.ntask <= Wk.max_tasks, CP_EINTERNAL, "a DP round has more tasks than the task buffers hold");
         RoundCounts *rc = Wk.rc.p + rd;
         const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
+        // In the rounds above the gap rounds the flattened stage (tile table, stream, two scans, span / open / fix: six dependent
+        // launches, ~40 us) typically serves three or four medium tasks.  Where the last layer that ran it saw at most 32, every task
+        // that is not finished in setup gets tiles of its own instead, and the stage disappears from the round.
+        const bool forced = allow_force && own_tiles && !gap && !R.isA && (size_t)rd < Wk.force_own.size() && Wk.force_own[(size_t)rd] &&
+                            (rhi - rlo + 1) <= 2 * Wk.force_rows && !(g_opt_dbg & 524288);
+        any_forced |= forced;
         if (!R.isA) {
             int64_t cols = (((n >> R.tau) + 1) >> 1) << R.tau;
             ProfScope ps(PROF_RPASS, s, 4.0 * (avg_deg + self_deg) * (double)cols + 8.0 * (double)R.ntask);
@@ -2536,7 +2547,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
 #define SS_ARGS R, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.cr.p, Wk.crl.p, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,   \
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
-                Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(gap ? g_opt_gap_min : g_opt_own_min),                                         \
+                Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(forced ? 2 : gap ? g_opt_gap_min : g_opt_own_min),                                         \
                 (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr, Wk.w_anch.p, Wk.w_anch2.p
             const int sbs = (int)g_opt_setup_bs;          // lanes per block: one list atomic per block, but the block's waves meet at two barriers
             dim3 sgrid((unsigned)cdiv(R.ntask, sbs));
@@ -2766,8 +2777,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     bool ok = true;
     for (int rd = 0; rd < NR; rd++) {
         const RoundCounts &g = got[(size_t)rd], &u = used[(size_t)rd];
-        CP_REQUIRE(!(g.err && !spec), CP_EINTERNAL, "DP work list overflow");
-        if (g.err) ok = false;                                                                  // a buffer was too small
+        CP_REQUIRE(!(g.err && !spec && !any_forced), CP_EINTERNAL, "DP work list overflow");
+        if (g.err) ok = false;                                                                  // a buffer was too small (the caller runs the layer again, plainly)
         if (g.nown > 0 && g.NT > 0 && !(u.nown > 0 && u.NT > 0)) ok = false;                    // a stage was skipped
         if (g.nlong > 0 && g.T > 0 && !(u.nlong > 0 && u.T > 0)) ok = false;
     }
@@ -2778,6 +2789,14 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 g_prof_pending[pt.idx].bytes = (pt.kind == 0 ? (double)g.own_steps : (double)g.T) * step_bytes;
         }
         Wk.pred = got; Wk.pred_ok = true; Wk.pred_rlo = rlo; Wk.pred_rhi = rhi; Wk.pred_win = G.win; Wk.pred_w = G.w;
+        if (allow_force && 2 * (rhi - rlo + 1) >= Wk.force_rows) {
+            Wk.force_own.resize((size_t)NR, 0);
+            Wk.force_rows = rhi - rlo + 1;
+            for (int rd = 1; rd < NR; rd++) {
+                const RoundCounts &g = got[(size_t)rd];
+                if (g.nlong > 0) Wk.force_own[(size_t)rd] = g.nlong <= 32;         // (a forced round reports none: its flag stays)
+            }
+        }
     }
     return ok;
 }
@@ -2794,7 +2813,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
         // (the shape is recorded only after every allocation succeeded: a hipMalloc failure leaves n == -1 and the next call starts over)
-        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.win_built = false;      // (the window anchors of a hyperedge model carry a second array)
+        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.win_built = false; Wk.force_own.clear(); Wk.force_rows = 0;      // (the window anchors of a hyperedge model carry a second array)
         Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
@@ -2846,10 +2865,12 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         if (!G.win || a < 1 || b < 1 || b > 2.0 * a) spec = false;
         else Wk.pred_scale = b / a;
     }
+    if (Wk.pred_win != G.win || Wk.pred_w != G.w || (int)Wk.force_own.size() != (G.win ? G.s + 1 : Wk.nbits) + 1) { Wk.force_own.clear(); Wk.force_rows = 0; }      // (another geometry: other rounds)
     if (run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, spec)) return;
     // the prediction missed (a stage that had been empty, or a buffer too small): the same layer again with exact counts
     g_spec_redo++;
-    bool ok = run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, false);
+    Wk.force_own.clear(); Wk.force_rows = 0;
+    bool ok = run_layer<TC>(A, M, alpha, W, cst_out, ptr_out, Wk, rlo, rhi, false, false);
     CP_REQUIRE(ok, CP_EINTERNAL, "DP layer failed with exact counts");
 }
 
@@ -2886,7 +2907,7 @@ template int dp_total_block_tables<double>(cp_csr_s *, void *, int64_t *, int64_
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
-template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; W->win_built = false; }
+template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; W->win_built = false; W->force_own.clear(); W->force_rows = 0; }
 template <typename TC> void *dp_total_work_get(cp_csr_s *A)
 {
     const int i = sizeof(TC) == sizeof(double) && ((TC)0.5 != (TC)0) ? 1 : 0;
