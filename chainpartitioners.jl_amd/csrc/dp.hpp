@@ -53,6 +53,7 @@ extern int64_t g_opt_fixed_point;              // 1: layers after a layer that r
 extern int64_t g_opt_nospec;                   // 1: every layer waits for its exact counts (one host sync per round)
 extern int64_t g_spec_redo;                    // layers redone because the prediction missed (diagnostics)
 extern int64_t g_opt_rpass_small_tau;           // rounds tau <= this use one lane per row in the right-part pass
+extern int64_t g_opt_force_max;                 // see run_layer (force_own)
 extern int64_t g_opt_setup_bs;                  // lanes per block of k_setup_short
 extern int64_t g_opt_rpass_cap;                 // lane-private entries per row in k_rpass_small, per cent of the mean (200)
 extern int64_t g_opt_rpass_ch;                 // columns per wave in k_rpass_wave (power of two >= 16)

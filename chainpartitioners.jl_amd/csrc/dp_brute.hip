@@ -21,6 +21,7 @@ int64_t g_opt_short_t = 8, g_opt_short_e = 64;
 int64_t g_opt_own_min = 64;
 int64_t g_opt_rpass_ch = 256;
 int64_t g_opt_rpass_small_tau = 4;
+int64_t g_opt_force_max = 1024;           // a round's flattened stage is replaced by own tiles when it served at most this many tasks
 int64_t g_opt_setup_bs = 1024;          // lanes per block of k_setup_short (a multiple of 64, at most 1024)
 int64_t g_opt_rpass_cap = 200;          // lane-private entries per row in k_rpass_small, per cent of the mean
 int64_t g_opt_nospec = 0, g_spec_redo = 0;

@@ -2521,7 +2521,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundCounts *rc = Wk.rc.p + rd;
         const bool gap = gaps && !R.isA && R.tau <= g_opt_gap_tau;       // long tasks of this round finish all the rows of their gap
         // In the rounds above the gap rounds the flattened stage (tile table, stream, two scans, span / open / fix: six dependent
-        // launches, ~40 us) typically serves three or four medium tasks.  Where the last layer that ran it saw at most 32, every task
+        // launches, ~40 us) typically serves three or four medium tasks.  Where the last layer that ran it saw at most force_max (1024), every task
         // that is not finished in setup gets tiles of its own instead, and the stage disappears from the round.
         const bool forced = allow_force && own_tiles && !gap && !R.isA && (size_t)rd < Wk.force_own.size() && Wk.force_own[(size_t)rd] &&
                             (rhi - rlo + 1) <= 2 * Wk.force_rows && !(g_opt_dbg & 524288);
@@ -2794,7 +2794,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             Wk.force_rows = rhi - rlo + 1;
             for (int rd = 1; rd < NR; rd++) {
                 const RoundCounts &g = got[(size_t)rd];
-                if (g.nlong > 0) Wk.force_own[(size_t)rd] = g.nlong <= 32;         // (a forced round reports none: its flag stays)
+                if (g.nlong > 0) Wk.force_own[(size_t)rd] = g.nlong <= g_opt_force_max;         // (a forced round reports none: its flag stays)
             }
         }
     }

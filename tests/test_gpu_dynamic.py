@@ -141,12 +141,12 @@ def test_no_read_before_write_in_round_buffers(hip, orc):
 #   dbg 512    every gap tile takes the entry-by-entry path (as if it held too many specials)
 LAYER_OPTIONS = [{"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 0}, {"gap_tau": 3, "gap_min": 8}, {"gap_tau": 8, "gap_min": 16}, {"gap_tau": 12},
                  {"ra_cache": 0}, {"ra_cache": 0, "gap_tau": -1, "nospec": 1}, {"dbg": 512}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
-                 {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 262144}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30},
+                 {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"force_max": 1000000}, {"dbg": 262144}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30},
                  # mispredictions: stages skipped although they have work / buffers too small -- the layer must notice and redo itself
                  {"dbg": 1024}, {"dbg": 2048}, {"dbg": 1024 + 2048, "gap_tau": -1},
                  # layers after one that reproduced its input row are copied (exact; off by default)
                  {"fixed_point": 1}]
-LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 6, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "setup_bs": 1024, "fixed_point": 0}
+LAYER_DEFAULTS = {"nospec": 0, "gap_tau": 6, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "fixed_point": 0}
 
 
 @pytest.mark.parametrize("oi", range(len(LAYER_OPTIONS)))
