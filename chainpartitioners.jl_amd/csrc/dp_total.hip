@@ -98,6 +98,7 @@ struct RoundDesc {
     // its right, so nothing bounds the rows next to it from the left; with opt[b][n] known first, they start there instead of
     // at the block start -- which every round would otherwise re-scan (n is not a power of two: ~n steps per round)
     int32_t nlast, last_b[31];
+    int32_t skip_std, _pad2;    // windowed round A: the standard heads (bit b of the row set, b < s) come from the cached counts (k_ra_cols)
 };
 
 // Per-round counters, on the device (one record per round, kept for the whole layer).  Kernels read their loop bounds from
@@ -509,6 +510,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         const int64_t n1 = R.n + 1;
         int64_t cs, ce;
         if (!geo_block(R.G, r, b, cs, ce)) live = false;
+        else if (R.isA && R.skip_std && b < R.G.s && ((r >> b) & 1)) live = false;      // (a standard head: done by k_ra_cols)
         else if (R.isA) {
             B = ce; a = cs;
             if (ce != r) { S0 = anch[R.aoff[b] + (r >> (b + 1))]; if (HYP) S0l = anch2[R.aoff[b] + (r >> (b + 1))]; }
@@ -2515,6 +2517,32 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             }
             CP_HIP(hipGetLastError());
             R.a_nmain = 0; R.ntask = R.nextra + R.nlast;
+        }
+        if (rd == 0 && g_opt_ra_cache && G.win && G.s >= 1 && n >= 1 && 4 * (rhi - rlo + 1) >= n && !(g_opt_dbg & 1048576)) {
+            // Windowed layer: the STANDARD heads of round A (rows with ctz == b < s, block [r - 2^b, r)) are the unconstrained scheme's
+            // round-A rows of the levels below s -- same blocks, same layer-independent counts: k_ra_cols computes them for all rows
+            // from the cache (60 B per candidate) and the generic round keeps the mirrored and common heads only.  (Worth it when the
+            // layer's window is a good part of the rows: the kernel does every row.)
+            if (!Wk.ra_built) { ProfScope ps(PROF_LINKS, s, 0.0); ra_build<TC>(A, Wk); }
+            RATab T2 = Wk.ra_tab;
+            T2.nbits = std::min<int32_t>(G.s, Wk.ra_tab.nbits);
+            const int64_t nrow2 = T2.nbits > 9 ? Wk.ra_tab.rbase[T2.nbits] : 0;
+            ProfScope ps(PROF_RA, s, 60.0 * (double)n);
+            const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
+            if (hyp) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
+                if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
+                                                  Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
+            } else {
+                auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa);
+                if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
+                                                  pa, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
+            }
+            CP_HIP(hipGetLastError());
+            R.skip_std = 1;
         }
         if (R.ntask <= 0) continue;
         CP_REQUIRE(R.ntask <= Wk.max_tasks, CP_EINTERNAL, "a DP round has more tasks than the task buffers hold");
