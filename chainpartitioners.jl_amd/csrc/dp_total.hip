@@ -2061,12 +2061,13 @@ template <typename TC, bool HYP>
 __global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restrict__ cnt, const int32_t *__restrict__ cnt2,
                                                  const int32_t *__restrict__ pos, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
-                                                 Best<TC, HYP> *__restrict__ part)
+                                                 Best<TC, HYP> *__restrict__ part, int64_t tile0, int64_t tile1)
 {
+    // tiles [tile0, tile1) of 256 columns (a windowed layer needs the rows near its window only)
     const int lane = threadIdx.x & 63;
     const int64_t n = T.n, n1 = n + 1;
-    const int64_t P0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LT;
-    if (P0 >= n) return;                                    // (wave-uniform) candidates are the columns 0 .. n - 1
+    const int64_t P0 = (tile0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LT;
+    if (P0 >= n || P0 >= tile1 * LT) return;                // (wave-uniform) candidates are the columns 0 .. n - 1
     const int64_t p0 = P0 + 4 * lane;
     TC wv[4]; int32_t pv[4];
 #pragma unroll
@@ -2497,10 +2498,10 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
             if (colmajor && hyp)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, (int64_t)0, cdiv(n, LT));
             else if (colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p));
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p), (int64_t)0, cdiv(n, LT));
             if (hyp) {
                 if (!colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p, Wk.ra_c2.p,
@@ -2518,26 +2519,28 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             CP_HIP(hipGetLastError());
             R.a_nmain = 0; R.ntask = R.nextra + R.nlast;
         }
-        if (rd == 0 && g_opt_ra_cache && G.win && G.s >= 1 && n >= 1 && 4 * (rhi - rlo + 1) >= n && !(g_opt_dbg & 1048576)) {
+        if (rd == 0 && g_opt_ra_cache && G.win && G.s >= 1 && n >= 1 && !(g_opt_dbg & 1048576)) {
             // Windowed layer: the STANDARD heads of round A (rows with ctz == b < s, block [r - 2^b, r)) are the unconstrained scheme's
             // round-A rows of the levels below s -- same blocks, same layer-independent counts: k_ra_cols computes them for all rows
-            // from the cache (60 B per candidate) and the generic round keeps the mirrored and common heads only.  (Worth it when the
-            // layer's window is a good part of the rows: the kernel does every row.)
+            // from the cache (60 B per candidate) and the generic round keeps the mirrored and common heads only.  The heads the layer
+            // reads are those make_round lists -- within 2^(b+1) of the row tile in plane b <= s: their blocks start at rlo - 3 * 2^s or later.
             if (!Wk.ra_built) { ProfScope ps(PROF_LINKS, s, 0.0); ra_build<TC>(A, Wk); }
             RATab T2 = Wk.ra_tab;
             T2.nbits = std::min<int32_t>(G.s, Wk.ra_tab.nbits);
             const int64_t nrow2 = T2.nbits > 9 ? Wk.ra_tab.rbase[T2.nbits] : 0;
-            ProfScope ps(PROF_RA, s, 60.0 * (double)n);
-            const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
+            const int64_t c_lo = std::max<int64_t>(0, (rlo > 0 ? rlo : 0) - ((int64_t)4 << G.s)), c_hi = std::min<int64_t>(n, rhi);
+            const int64_t tile0 = c_lo / LT, tile1 = cdiv(c_hi, LT);
+            ProfScope ps(PROF_RA, s, 60.0 * (double)(tile1 - tile0) * LT);
+            const unsigned cgrid = (unsigned)std::max<int64_t>(1, cdiv(tile1 - tile0, 4));
             if (hyp) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p);
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, tile0, tile1);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
             } else {
                 auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa);
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa, tile0, tile1);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   pa, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
             }
