@@ -98,7 +98,7 @@ struct RoundDesc {
     // its right, so nothing bounds the rows next to it from the left; with opt[b][n] known first, they start there instead of
     // at the block start -- which every round would otherwise re-scan (n is not a power of two: ~n steps per round)
     int32_t nlast, last_b[31];
-    int32_t skip_std, _pad2;    // windowed round A: the standard heads (bit b of the row set, b < s) come from the cached counts (k_ra_cols)
+    int32_t skip_std, skip_mir; // windowed round A: the standard / mirrored heads (bit b of the row set / clear, b < s) come from the cached counts
 };
 
 // Per-round counters, on the device (one record per round, kept for the whole layer).  Kernels read their loop bounds from
@@ -511,6 +511,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         int64_t cs, ce;
         if (!geo_block(R.G, r, b, cs, ce)) live = false;
         else if (R.isA && R.skip_std && b < R.G.s && ((r >> b) & 1)) live = false;      // (a standard head: done by k_ra_cols)
+        else if (R.isA && R.skip_mir && b < R.G.s && !((r >> b) & 1)) live = false;     // (a mirrored head: done by k_ra_layer on the mirrored table)
         else if (R.isA) {
             B = ce; a = cs;
             if (ce != r) { S0 = anch[R.aoff[b] + (r >> (b + 1))]; if (HYP) S0l = anch2[R.aoff[b] + (r >> (b + 1))]; }
@@ -1932,7 +1933,17 @@ __global__ void __launch_bounds__(256) k_win_anchors(RoundDesc R, int64_t nitems
 // partition and kept (4 B each); a layer then evaluates round A by streaming counts, W and pos (16 B per candidate instead
 // of the candidate's whole column).  Elements are stored level by level (b), row by row, candidate p = r - 1 - i at index i;
 // every level is padded to whole tiles of LT elements.
-struct RATab { int32_t nbits, _pad; int64_t n; int64_t tbase[33]; int64_t rbase[33]; };      // tiles of level b: [tbase[b], tbase[b+1]); rows of the levels >= 9: [rbase[b], rbase[b+1])
+// tiles of level b: [tbase[b], tbase[b+1]); rows of the levels >= 9: [rbase[b], rbase[b+1]).
+// mir_w = 0: the unconstrained scheme's round-A rows -- level b holds the rows r = (2u+1) 2^b, candidates r - 1 - i, i < 2^b.
+// mir_w = w > 0: the MIRRORED heads of the windowed geometry (geo_block) -- level b < s holds the rows r = (u+1) 2^(b+1),
+// candidates ce - 1 - i with ce = r + 2^(b+1) - 1 - w (those below column 0 do not exist); the counts carry the head's anchor
+// nets(ce, r), at aoff[b] + (r >> (b+1)) of the window anchors.  tlo / thi: the tiles of each level a windowed layer needs.
+struct RATab { int32_t nbits, _pad; int64_t n; int64_t tbase[33]; int64_t rbase[33]; int64_t mir_w; int64_t aoff[33]; int64_t tlo[33], thi[33]; };
+
+__device__ __forceinline__ int64_t ra_row(const RATab &T, int b, int64_t u)
+{
+    return T.mir_w ? (u + 1) << (b + 1) : ((u << 1) | 1) << b;
+}
 
 __device__ __forceinline__ bool ra_decode(const RATab &T, int64_t tile, int j, int &b, int64_t &r, int64_t &p, int64_t &i)
 {
@@ -1941,9 +1952,9 @@ __device__ __forceinline__ bool ra_decode(const RATab &T, int64_t tile, int j, i
     int64_t e = (tile - T.tbase[b]) * LT + j;               // element inside the level
     int64_t u = e >> b;
     i = e & (((int64_t)1 << b) - 1);
-    r = ((u << 1) | 1) << b;
-    p = r - 1 - i;
-    return r <= T.n;
+    r = ra_row(T, b, u);
+    p = (T.mir_w ? r + ((int64_t)2 << b) - 1 - T.mir_w : r) - 1 - i;
+    return r <= T.n && p >= 0;
 }
 
 // d[E] = #{q in column p : next[q] >= r} (d2: rows whose first column is p and whose last column is < r)
@@ -1965,12 +1976,14 @@ __global__ void __launch_bounds__(256) k_ra_colcount(RATab T, const int32_t *__r
 }
 
 // c[E] = sum of d over the row's elements 0 .. i  (G = exclusive prefix sums of d over all elements)
-__global__ void __launch_bounds__(256) k_ra_final(RATab T, const int64_t *__restrict__ G, int32_t *__restrict__ c)
+__global__ void __launch_bounds__(256) k_ra_final(RATab T, const int64_t *__restrict__ G, int32_t *__restrict__ c, const int32_t *__restrict__ anch)
 {
     int b; int64_t r, p, i;
     ra_decode(T, blockIdx.x, threadIdx.x, b, r, p, i);
     int64_t E = (int64_t)blockIdx.x * LT + threadIdx.x;
-    c[E] = (int32_t)(G[E + 1] - G[E - i]);
+    int32_t v = (int32_t)(G[E + 1] - G[E - i]);
+    if (anch && r <= T.n) v += anch[T.aoff[b] + (r >> (b + 1))];            // (mirrored heads: the part [ce, r) the block's columns stand on)
+    c[E] = v;
 }
 
 template <typename TC, bool HYP>
@@ -1999,12 +2012,13 @@ __global__ void __launch_bounds__(256) k_ra_layer(RATab T, int64_t ntile, const 
     int b = 0;
     int64_t r0, p0, i0;
     const bool ok0 = ra_decode(T, tile, 4 * lane, b, r0, p0, i0);
+    if (tile < T.tlo[b] || tile >= T.thi[b]) return;        // (uniform) a windowed layer: rows far from its window
     Best<TC, HYP> cand[4];
     int64_t rk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int64_t r = r0, p = p0 - k;
-        bool ok = ok0;
+        bool ok = ok0 && p >= 0;                            // (mirrored heads: a block may be cut off at column 0)
         if (b < 2) { int bb; int64_t ii; ok = ra_decode(T, tile, 4 * lane + k, bb, r, p, ii); }      // (uniform branch)
         rk[k] = ok ? r : 0;
         best_clear(cand[k]);
@@ -2150,7 +2164,7 @@ __global__ void __launch_bounds__(256) k_ra_merge(RATab T, int64_t nrow, const B
     if (w >= nrow) return;
     int b = 9;
     while (w >= T.rbase[b + 1]) b++;
-    const int64_t u = w - T.rbase[b], r = ((u << 1) | 1) << b, n1 = T.n + 1;
+    const int64_t u = w - T.rbase[b], r = ra_row(T, b, u), n1 = T.n + 1;
     const int64_t t0 = T.tbase[b] + (u << (b - 8)) - T.tbase[9], cntt = (int64_t)1 << (b - 8);
     Best<TC, HYP> x; best_clear(x);
     // (the top row's block is half the matrix -- 2^15 partials at n = 10^7: eight loads per lane in flight; one at a time, that row
@@ -2205,6 +2219,9 @@ struct LayerWork {
     DBuf<int32_t> o_spv;                                // ... and the specials between them
     // round A from cached counts
     bool ra_built = false; RATab ra_tab; int64_t ra_ntile = 0, ra_nrow = 0;
+    bool mir_built = false; RATab mir_tab; int64_t mir_ntile = 0, mir_nrow = 0, mir_w = 0;      // the mirrored heads of a window width (ra_build_mir)
+    DBuf<int32_t> mir_c, mir_c2;
+    DBuf<Best<TC, true>> mir_part;
     DBuf<int32_t> ra_c, ra_c2;
     DBuf<int64_t> ra_G;                                 // prefix sums while the counts are built
     DBuf<Best<TC, true>> ra_part;
@@ -2388,6 +2405,7 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
     RATab &T = Wk.ra_tab;
     memset(&T, 0, sizeof(T));
     T.nbits = Wk.nbits; T.n = n;
+    for (int b = 0; b < 33; b++) { T.tlo[b] = 0; T.thi[b] = INT64_MAX; }
     int64_t tb = 0, rb = 0;
     for (int b = 0; b < 33; b++) {
         T.tbase[b] = tb; T.rbase[b] = rb;
@@ -2407,10 +2425,10 @@ static void ra_build(cp_csr_s *A, LayerWork<TC> &Wk)
     hipLaunchKernelGGL(k_ra_colcount, dim3((unsigned)tb), dim3(LT), 0, s, T, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,
                        hyp ? A->flast.p : (const int32_t *)nullptr, Wk.ra_c.p, hyp ? Wk.ra_c2.p : (int32_t *)nullptr);
     exclusive_scan_i32(Wk.ra_c.p, G.p, (int64_t)total, scratch, s);
-    hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c.p);
+    hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c.p, (const int32_t *)nullptr);
     if (hyp) {
         exclusive_scan_i32(Wk.ra_c2.p, G.p, (int64_t)total, scratch, s);
-        hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c2.p);
+        hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, G.p, Wk.ra_c2.p, (const int32_t *)nullptr);
     }
     CP_HIP(hipGetLastError());
     Wk.ra_built = true;
@@ -2450,6 +2468,47 @@ static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
 }
 
 constexpr int64_t LB_MAX = 1 << 20;      // largest scan (elements) done in a single launch
+
+// the same for the mirrored heads of the windowed geometry (once per pattern and window width; after win_build: the counts carry
+// the heads' anchors)
+template <typename TC>
+static void ra_build_mir(cp_csr_s *A, LayerWork<TC> &Wk)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n;
+    const bool hyp = Wk.hyp;
+    const Geo G = Wk.G;
+    RATab &T = Wk.mir_tab;
+    memset(&T, 0, sizeof(T));
+    T.nbits = G.s; T.n = n; T.mir_w = G.w;
+    for (int b = 0; b < 33; b++) { T.tlo[b] = 0; T.thi[b] = INT64_MAX; T.aoff[b] = b < 32 ? Wk.win_aoff[b] : 0; }
+    int64_t tb = 0, rb = 0;
+    for (int b = 0; b < 33; b++) {
+        T.tbase[b] = tb; T.rbase[b] = rb;
+        if (b >= G.s) continue;
+        const int64_t nrows = n >> (b + 1);                  // rows (u + 1) 2^(b+1) <= n
+        tb += cdiv(nrows << b, LT);
+        if (b >= 9) rb += nrows;
+    }
+    Wk.mir_ntile = tb; Wk.mir_nrow = rb;
+    const size_t total = (size_t)tb * LT;
+    Wk.mir_c.ensure(total + 8);
+    if (hyp) Wk.mir_c2.ensure(total + 8);
+    Wk.mir_part.ensure((size_t)std::max<int64_t>(1, tb - T.tbase[9]));
+    Wk.mir_built = true; Wk.mir_w = G.w;
+    if (tb <= 0) return;
+    DBuf<int64_t> &Gs = Wk.ra_G, &scratch = Wk.scratch;
+    Gs.ensure(total + 1);
+    hipLaunchKernelGGL(k_ra_colcount, dim3((unsigned)tb), dim3(LT), 0, s, T, A->pos32.p, A->next.p, hyp ? A->fpos32.p : (const int32_t *)nullptr,
+                       hyp ? A->flast.p : (const int32_t *)nullptr, Wk.mir_c.p, hyp ? Wk.mir_c2.p : (int32_t *)nullptr);
+    exclusive_scan_i32(Wk.mir_c.p, Gs.p, (int64_t)total, scratch, s);
+    hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, Gs.p, Wk.mir_c.p, (const int32_t *)Wk.w_anch.p);
+    if (hyp) {
+        exclusive_scan_i32(Wk.mir_c2.p, Gs.p, (int64_t)total, scratch, s);
+        hipLaunchKernelGGL(k_ra_final, dim3((unsigned)tb), dim3(LT), 0, s, T, Gs.p, Wk.mir_c2.p, (const int32_t *)Wk.w_anch2.p);
+    }
+    CP_HIP(hipGetLastError());
+}
 
 // Runs the rounds of one layer.  `spec`: the per-round counts of the PREVIOUS layer (Wk.pred) size the grids, the buffers and
 // decide which stages are launched; every kernel reads its true loop bounds from the device (RoundCounts) and walks them with
@@ -2546,6 +2605,36 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             }
             CP_HIP(hipGetLastError());
             R.skip_std = 1;
+            if (!(g_opt_dbg & 2097152)) {
+                // the MIRRORED heads the same way, from their own table (row-major kernel; per level the tiles of the rows near the window)
+                if (!Wk.mir_built || Wk.mir_w != G.w) { ProfScope ps2(PROF_LINKS, s, 0.0); ra_build_mir<TC>(A, Wk); }
+                if (Wk.mir_ntile > 0) {
+                    RATab T3 = Wk.mir_tab;
+                    const int64_t r_lo = std::max<int64_t>(1, (rlo > 0 ? rlo : 0) - ((int64_t)4 << G.s)), r_hi = std::min<int64_t>(n, rhi);
+                    double elems = 0;
+                    for (int b = 0; b < T3.nbits; b++) {
+                        const int64_t u_lo = std::max<int64_t>(0, (r_lo >> (b + 1)) - 1), u_hi = r_hi >> (b + 1);        // rows u_lo .. u_hi - 1
+                        T3.tlo[b] = T3.tbase[b] + ((u_lo << b) / LT);
+                        T3.thi[b] = std::min<int64_t>(T3.tbase[b + 1], T3.tbase[b] + cdiv(std::max<int64_t>(u_hi, 0) << b, LT));
+                        elems += (double)std::max<int64_t>(0, T3.thi[b] - T3.tlo[b]) * LT;
+                    }
+                    ProfScope ps2(PROF_RA, s, 16.0 * elems);
+                    if (hyp) {
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p, Wk.mir_c2.p,
+                                           A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p);
+                        if (Wk.mir_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(Wk.mir_nrow, 4)), dim3(256), 0, s, T3, Wk.mir_nrow,
+                                                                Wk.mir_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
+                    } else {
+                        auto *pm = reinterpret_cast<Best<TC, false> *>(Wk.mir_part.p);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, false>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p,
+                                           (const int32_t *)nullptr, A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm);
+                        if (Wk.mir_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(Wk.mir_nrow, 4)), dim3(256), 0, s, T3, Wk.mir_nrow,
+                                                                pm, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
+                    }
+                    CP_HIP(hipGetLastError());
+                    R.skip_mir = 1;
+                }
+            }
         }
         if (R.ntask <= 0) continue;
         CP_REQUIRE(R.ntask <= Wk.max_tasks, CP_EINTERNAL, "a DP round has more tasks than the task buffers hold");
@@ -2844,7 +2933,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
     CP_REQUIRE(nbits <= NBMAX, CP_EINVAL, "n exceeds the bit-plane budget");
     if (Wk.n != n || Wk.hyp != hyp) {
         // (the shape is recorded only after every allocation succeeded: a hipMalloc failure leaves n == -1 and the next call starts over)
-        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.win_built = false; Wk.force_own.clear(); Wk.force_rows = 0;      // (the window anchors of a hyperedge model carry a second array)
+        Wk.n = -1; Wk.nbits = nbits; Wk.hyp = hyp; Wk.pred_ok = false; Wk.ra_built = false; Wk.win_built = false; Wk.mir_built = false; Wk.force_own.clear(); Wk.force_rows = 0;      // (the window anchors of a hyperedge model carry a second array)
         Wk.o_rec.release(); Wk.loc.release();       // (the per-tile arrays are re-made for the new shape on first use)
         size_t plane = (size_t)nbits * (size_t)(n + 1);
         Wk.opt.alloc(plane); Wk.nnopt.alloc(plane); Wk.cr.alloc(plane);
@@ -2938,7 +3027,7 @@ template int dp_total_block_tables<double>(cp_csr_s *, void *, int64_t *, int64_
 
 template <typename TC> void *dp_total_work_new() { return new LayerWork<TC>(); }
 template <typename TC> static void work_free_fn(void *w) { delete reinterpret_cast<LayerWork<TC> *>(w); }
-template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; W->win_built = false; W->force_own.clear(); W->force_rows = 0; }
+template <typename TC> static void work_reset_fn(void *w) { auto *W = reinterpret_cast<LayerWork<TC> *>(w); W->ra_built = false; W->pred_ok = false; W->win_built = false; W->mir_built = false; W->force_own.clear(); W->force_rows = 0; }
 template <typename TC> void *dp_total_work_get(cp_csr_s *A)
 {
     const int i = sizeof(TC) == sizeof(double) && ((TC)0.5 != (TC)0) ? 1 : 0;

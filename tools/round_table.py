@@ -11,7 +11,8 @@ def short(n):
     return name
 names = [short(r['Kernel_Name']) for r in rows]
 idx = [i for i, n in enumerate(names) if n.startswith('k_combine')]
-lo, hi = idx[0] + 1, idx[1] + 1
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # which layer: the one between the L-th and (L+1)-th combine
+lo, hi = idx[L] + 1, idx[L + 1] + 1
 rounds, cur = [], collections.OrderedDict()
 for r, n in zip(rows[lo:hi], names[lo:hi]):
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
