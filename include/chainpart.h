@@ -213,7 +213,8 @@ int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
  * "own_min" (shortest task with tiles of its own), "gap_tau"/"gap_min" (gap passes: rounds and task lengths; -1: none),
  * "ra_cache" (round A from counts cached per partition), "nospec" 1 (one host sync per round instead of sizing a layer from the
  * previous one), "rpass_ch"/"rpass_small_tau"/"rpass_cap" (right-part passes: columns per wave, last
- * lane-per-row round, lane-private share of a row in per cent of the mean), "setup_bs" (lanes per block of the task setup), "bn_chunk"
+ * lane-per-row round, lane-private share of a row in per cent of the mean), "setup_bs" (lanes per block of the task setup), "force_max" (a round whose flattened
+ * stage served at most this many tasks gives them tiles of their own from the next layer on), "bn_chunk"
  * (rows per walk of the bottleneck DP), "prof_only" slot (events on one profile slot only), "dbg"
  * (diagnostic bit mask).  Unknown names return CP_EINVAL. */
 int32_t cp_set_option(const char *name, int64_t value);
