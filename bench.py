@@ -157,7 +157,8 @@ class DpBench:
         hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does
         if self.tiled:
             from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
-            meth = self.cp.DynamicBottleneckSplitter(self.mdl) if self.combine else self.cp.DynamicTotalSplitter(self.mdl)
+            cost = self.cp.ConstrainedCost(self.mdl, self.cp.VertexCount(), self.w) if self.cfg == "constrained" else self.mdl
+            meth = self.cp.DynamicBottleneckSplitter(cost) if self.combine else self.cp.DynamicTotalSplitter(cost)
             self.spl[:] = partition_stripe_tiled(hip, h, self.n, self.K, meth, device=self.dev)
             return
         rc = hip.partition_dynamic(h, self.K, self.combine, 0, self.mm, None, self.wm, self.w, float(self.w), self.spl)
@@ -192,7 +193,7 @@ class DpBench:
 
 
 def run_dp(args, cfg, dev, rank, world, dist):
-    tiled = args.mode == "tiled" and world > 1
+    tiled = args.mode == "tiled" and dist is not None
     B = DpBench(args, cfg, dev, rank, world, tiled)
     hip, n, N, K = B.hip, B.n, B.N, B.K
     for kv in args.opt:
@@ -433,9 +434,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "tiled":
+        # (--mode tiled on one GPU: a one-rank RCCL group, so that the row-tiled driver and its collectives can be timed on a one-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:

@@ -102,13 +102,18 @@ def test_tiled_constrained_tables_equal_the_oracle(hip, orc):
     assert nondeg > 20
 
 
-def _tiled_worker(rank, world, port, q):
+def _tiled_worker(rank, world, port, q, backend="gloo"):
     import os, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import cpamd
     cpm = cpamd.load()
     from chainpartitioners_jl_amd import _lib
@@ -151,3 +156,26 @@ def test_tiled_two_processes_gloo(hip, orc):
                       cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
     assert got == want
     assert len(set(want[1])) > 2 and len(set(want[2])) > 2          # the last two are informative
+
+
+def test_tiled_one_rank_over_rccl(hip, orc):
+    """The tiled driver with the RCCL backend (backend "nccl"), one rank on this box's GPU: the per-layer all_gather_into_tensor of
+    the cost tiles and the MAX all-reduces of unravel_splits go through RCCL on device tensors, ordered with the library's kernels
+    by stream only (cp_set_stream on torch's current stream) -- the code path of bench.py --mode tiled, which a one-GPU box cannot
+    run with more ranks.  Results against the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_tiled_worker, args=(0, 1, port, q, "nccl"))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    A = suitesparse_shaped(4000, 6, 11)
+    net = cp.AffineConnectivityModel(0, 10, 1, 100)
+    want = [cp.partition_stripe(A, 6, m, backend=orc).spl.tolist()
+            for m in (cp.DynamicTotalSplitter(net), cp.DynamicBottleneckSplitter(net),
+                      cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
+    assert got == want
