@@ -137,14 +137,14 @@ def test_config3_shape_constrained_and_bottleneck_dps(hip):
         full = np.minimum(1 + w * np.arange(K + 1, dtype=np.int64), n + 1)
         rc, ref = hip.objective(h, K, full, mm, None, 0)
         assert got <= ref
-        for opts in ({"nospec": 1}, {"gap_tau": -1}):
+        for opts in ({"nospec": 1}, {"gap_tau": -1}, {"dbg": 1048576}, {"dbg": 2097152}, {"force_max": 0}):      # (the last three: round A without its caches, no forced own tiles)
             for k_, v_ in opts.items():
                 hip.set_option(k_, v_)
             try:
                 spl2 = np.zeros(K + 1, dtype=np.int64)
                 assert hip.partition_dynamic(h, K, 0, 0, mm, None, wm, w, float(w), spl2) == 0, (opts, hip.last_error())
             finally:
-                hip.set_option("nospec", 0); hip.set_option("gap_tau", 6)
+                hip.set_option("nospec", 0); hip.set_option("gap_tau", 6); hip.set_option("dbg", 0); hip.set_option("force_max", 1024)
             assert np.array_equal(spl, spl2), opts
         # the chunker loop order fills the same tables
         spl3 = np.zeros(K + 1, dtype=np.int64)

@@ -129,3 +129,23 @@ def test_windowed_path_equals_literal_kernel_beyond_the_oracle(hip):
             finally:
                 hip.set_option("force_brute", 0)
             assert fast == lit
+
+
+def test_round_a_caches_change_no_table_cell_at_3e5(hip):
+    """Beyond the oracle's reach (s = 16: heads with blocks of up to 2^15 candidates, merged from tile partials): the complete
+    cst / ptr tables of the width-constrained DP with round A from the cached counts (default) equal those of the generic round A
+    (dbg 1048576: no cache at all; dbg 2097152: standard heads cached, mirrored ones streamed), connectivity and hyperedge costs."""
+    A = suitesparse_shaped(300000, 8, 3)
+    for mdl, K, w in ((cp.AffineConnectivityModel(0, 10, 1, 100), 6, 75001), (cp.AffineHyperedgeCutModel(0, 2, 1, 1, 3), 5, 131072),
+                      (cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0), 9, 40000)):
+        mm = mdl.marshal()
+        rc0, lo0, hi0, p0, c0 = hip.dynamic_tables_constrained(A, K, mm, w)
+        assert rc0 == 0, hip.last_error()
+        for dbg in (1048576, 2097152):
+            hip.set_option("dbg", dbg)
+            try:
+                rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w)
+            finally:
+                hip.set_option("dbg", 0)
+            assert rc1 == 0 and np.array_equal(lo0, lo1) and np.array_equal(hi0, hi1)
+            assert np.array_equal(p0, p1) and np.array_equal(c0, c1), (K, w, dbg)
