@@ -115,7 +115,7 @@ __device__ __forceinline__ bool bn_pred(const BnCtx<TC> &C, int64_t p, int64_t r
 template <typename TC>
 __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk, int stride, int coarse,
                                                    int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0,
-                                                   const int32_t *__restrict__ hint)
+                                                   const int32_t *__restrict__ hint, const int32_t *__restrict__ hint2)
 {
     // chunks t = 0, stride, 2 stride, ...; coarse != 0: those that are multiples of `coarse` are known already and bracket the rest
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int
         if (lo > hi) lo = hi;
     } else if (hint) {
         int64_t g = hint[t];
+        if (hint2) g += g - (int64_t)hint2[t];                // (the crossing of the layer before as well: continue its move)
         if (g < 0) g = 0;
         if (g > r) g = r;
         if (bn_pred(C, g, r)) {                             // the crossing is at or left of g: gallop left
@@ -227,8 +228,9 @@ __global__ void __launch_bounds__(256) k_bn_walk(BnCtx<TC> C, int64_t rlo, int64
 struct BnWork {
     bool have_net = false, have_self = false;
     WaveletHost net, self;
-    DBuf<int32_t> runend, blk, c0, nn0, nl0, hint;
+    DBuf<int32_t> runend, blk, c0, nn0, nl0, hint, hint2;
     int64_t hint_rlo = -1, hint_nchunk = -1, hint_ch = -1;      // the tiling the hints belong to (-1: none)
+    int hint_layers = 0;                                        // how many consecutive layers of that tiling the hints cover (hint: last, hint2: the one before)
 };
 
 static BnWork *bn_work_get(cp_csr_s *A)
@@ -236,7 +238,7 @@ static BnWork *bn_work_get(cp_csr_s *A)
     if (!A->bn_work) {
         A->bn_work = new BnWork();
         A->bn_work_free_fn = [](void *w) { delete reinterpret_cast<BnWork *>(w); };
-        A->bn_work_reset_fn = [](void *w) { auto *B = reinterpret_cast<BnWork *>(w); B->have_net = false; B->have_self = false; B->hint_nchunk = -1; };   // (cp_csr_reset_cache)
+        A->bn_work_reset_fn = [](void *w) { auto *B = reinterpret_cast<BnWork *>(w); B->have_net = false; B->have_self = false; B->hint_nchunk = -1; B->hint_layers = 0; };   // (cp_csr_reset_cache)
     }
     return reinterpret_cast<BnWork *>(A->bn_work);
 }
@@ -272,7 +274,8 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1024), 0, s, nblk, B->blk.p);
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
     const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
-    B->hint.ensure((size_t)nchunk);
+    if (!hinted) B->hint_layers = 0;
+    B->hint.ensure((size_t)nchunk); B->hint2.ensure((size_t)nchunk);
     // every 64th chunk from the previous layer's hint, the rest bracketed by those.  Tried, config 3 matrix, K = 64 (302 ms as is):
     //  - a level of every 8th chunk in between: 6 probes of the counter for most chunks instead of 9, but a third chain of
     //    dependent probes: 318 ms;
@@ -282,10 +285,12 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     //  - the fine starts as a 4-ary search, three interleaved descents per step: 1.0 ms against 0.9 ms -- 1.25 M lanes are bound by
     //    the number of line requests, not by the length of the chain.
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 64, 0, B->c0.p, B->nn0.p,
-                       B->nl0.p, hinted ? B->hint.p : (const int32_t *)nullptr);
+                       B->nl0.p, hinted ? B->hint.p : (const int32_t *)nullptr, hinted && B->hint_layers >= 2 && !(g_opt_dbg & 4194304) ? B->hint2.p : (const int32_t *)nullptr);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, 64, B->c0.p, B->nn0.p, B->nl0.p,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
+    std::swap(B->hint.p, B->hint2.p); std::swap(B->hint.n, B->hint2.n);      // (hint2 <- the previous layer's crossings)
     CP_HIP(hipMemcpyAsync(B->hint.p, B->c0.p, sizeof(int32_t) * (size_t)nchunk, hipMemcpyDeviceToDevice, s));
+    B->hint_layers++;
     B->hint_nchunk = nchunk; B->hint_rlo = rlo; B->hint_ch = CH;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
                        B->runend.p, cst_out, ptr_out);
