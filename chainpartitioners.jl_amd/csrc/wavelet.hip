@@ -23,6 +23,7 @@ static int32_t cllog2_i(int64_t x)      // util.jl:3-8 : ceil(log2(x)), cllog2(1
 
 // hot: a key that a large share of the entries carries (net keys: n + 1 = "no previous occurrence", one entry in ten on the bench
 // matrices) -- same-address atomics serialise in L2 (115 ms of a 270 ms build at N = 10^8), so its count is taken per wave
+// (Tried: bucket starts from a rocprim radix sort of the keys instead of this histogram: the build went from 75 to 266 ms at N = 10^8.)
 __global__ void __launch_bounds__(256) k_hist_keys(const int32_t *__restrict__ keys, int64_t Nk, int32_t *__restrict__ hist, int32_t hot)
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
