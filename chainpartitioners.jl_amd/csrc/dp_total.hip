@@ -570,35 +570,20 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
     }
     if (lane == 0) { s_wcnt[0][wv] = (int32_t)__popcll(ml); s_wcnt[1][wv] = (int32_t)__popcll(mo); s_wsteps[wv] = lsum; }
     __syncthreads();
+    int32_t base0 = 0, base1 = 0;
     if (threadIdx.x == 0) {
         int32_t t0 = 0, t1 = 0; unsigned long long st = 0;
         for (int w = 0, nw = (int)(blockDim.x >> 6); w < nw; w++) {
             int32_t c0 = s_wcnt[0][w], c1 = s_wcnt[1][w];
             s_wcnt[0][w] = t0; s_wcnt[1][w] = t1; t0 += c0; t1 += c1; st += s_wsteps[w];
         }
-        s_base[0] = t0 ? atomicAdd(nlong, t0) : 0;
-        s_base[1] = t1 ? atomicAdd(n_own, t1) : 0;
+        // (the two list positions come back from L2 while this lane, like all the others, finishes its short task below: the
+        //  block used to sit at a barrier for the length of these round trips)
+        base0 = t0 ? atomicAdd(nlong, t0) : 0;
+        base1 = t1 ? atomicAdd(n_own, t1) : 0;
         if (st) atomicAdd(own_steps, st);
     }
-    __syncthreads();
-    if (is_long) {
-        int32_t idx = s_base[0] + s_wcnt[0][wv] + __popcll(ml & ((1ull << lane) - 1ull));
-        tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
-        tb[idx] = (uint8_t)b;
-        len[idx] = (int32_t)(1 + (B - a));
-        if (HYP) tS0l[idx] = (int32_t)S0l;
-    }
-    if (is_own) {
-        int32_t idx = s_base[1] + s_wcnt[1][wv] + __popcll(mo & ((1ull << lane) - 1ull));
-        if (idx >= o_cap) { *err = 1; return; }          // (an own task is never short) cannot happen (LayerWork sizes the list for the worst case); never write outside
-        o_tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
-        o_tb[idx] = (uint8_t)b;
-        o_rlen[idx] = (int32_t)Lmine;
-        o_ntl[idx] = (int32_t)((Lmine + LT - 1) / LT);
-        if (HYP) o_tS0l[idx] = (int32_t)S0l;
-    }
-    // the short tasks are finished by their lanes -- AFTER the barriers above, so that no wave of the block waits for the lane with
-    // the longest walk
+    // the short tasks are finished by their lanes -- between the two barriers, while the list positions are on their way
     if (is_short) {
         const int64_t n1 = R.n + 1, L = 1 + (B - a);
         int64_t rw = (int64_t)b * n1 + PR(r);
@@ -636,6 +621,24 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             }
             opt[rw] = best.p; nnopt[rw] = best.nn; if (HYP) nlopt[rw] = best_nl(best);
         }
+    }
+    if (threadIdx.x == 0) { s_base[0] = base0; s_base[1] = base1; }
+    __syncthreads();
+    if (is_long) {
+        int32_t idx = s_base[0] + s_wcnt[0][wv] + __popcll(ml & ((1ull << lane) - 1ull));
+        tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
+        tb[idx] = (uint8_t)b;
+        len[idx] = (int32_t)(1 + (B - a));
+        if (HYP) tS0l[idx] = (int32_t)S0l;
+    }
+    if (is_own) {
+        int32_t idx = s_base[1] + s_wcnt[1][wv] + __popcll(mo & ((1ull << lane) - 1ull));
+        if (idx >= o_cap) { *err = 1; return; }          // (an own task is never short) cannot happen (LayerWork sizes the list for the worst case); never write outside
+        o_tdesc[idx] = make_int4((int32_t)B, (int32_t)S0, (int32_t)r, pos32[r]);
+        o_tb[idx] = (uint8_t)b;
+        o_rlen[idx] = (int32_t)Lmine;
+        o_ntl[idx] = (int32_t)((Lmine + LT - 1) / LT);
+        if (HYP) o_tS0l[idx] = (int32_t)S0l;
     }
 }
 
