@@ -2074,63 +2074,71 @@ __global__ void __launch_bounds__(256) k_ra_layer(RATab T, int64_t ntile, const 
 // P0 + 4 l .. + 3; the count elements of a row are stored by descending p (ra_decode), so a lane's four are one aligned vector.
 // Rows of up to 256 candidates (b <= 8) lie inside the wave's columns and are finished here (butterfly over the row's lanes);
 // longer rows leave one partial per 256 candidates for k_ra_merge, in the slot k_ra_layer would use.
-template <typename TC, bool HYP>
+template <typename TC, bool HYP, bool MIR>
 __global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restrict__ cnt, const int32_t *__restrict__ cnt2,
                                                  const int32_t *__restrict__ pos, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
                                                  Best<TC, HYP> *__restrict__ part, int64_t tile0, int64_t tile1)
 {
-    // tiles [tile0, tile1) of 256 columns (a windowed layer needs the rows near its window only)
+    // tiles [tile0, tile1) of 256 consecutive values of the coordinate z (a windowed layer needs the rows near its window only).
+    // MIR = false: z = p, the candidate p belongs to the level-b row of the block [r - 2^b, r) iff bit b of z is CLEAR.
+    // MIR = true (table with mir_w = w): z = p + w + 1, p belongs to the mirrored head rho = z with the bits <= b cleared
+    // (block [rho + 2^b - 1 - w, rho + 2^(b+1) - 1 - w)) iff bit b of z is SET.  In both maps a row's 2^b candidates are an aligned
+    // block of z and its elements run by descending z: element i = (2^b - 1) - (z mod 2^b).
     const int lane = threadIdx.x & 63;
-    const int64_t n = T.n, n1 = n + 1;
-    const int64_t P0 = (tile0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LT;
-    if (P0 >= n || P0 >= tile1 * LT) return;                // (wave-uniform) candidates are the columns 0 .. n - 1
-    const int64_t p0 = P0 + 4 * lane;
+    const int64_t n = T.n, n1 = n + 1, off = MIR ? T.mir_w + 1 : 0;
+    const int64_t Z0 = (tile0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LT;
+    if (Z0 - off >= n || Z0 >= tile1 * LT) return;          // (wave-uniform) candidates are the columns 0 .. n - 1
+    const int64_t z0 = Z0 + 4 * lane, p0 = z0 - off;
     TC wv[4]; int32_t pv[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int64_t p = p0 + k < n ? p0 + k : n; wv[k] = W[p]; pv[k] = pos[p]; }
+    for (int k = 0; k < 4; k++) { int64_t p = p0 + k; p = p < 0 ? 0 : p < n ? p : n; wv[k] = W[p]; pv[k] = pos[p]; }
     for (int b = 0; b < T.nbits; b++) {
-        if (b >= 8 && ((P0 >> b) & 1)) continue;            // (wave-uniform) the wave's columns have the bit set: no row of this level
-        // the lane's row of this level and its candidates among p0 .. p0 + 3
-        //   b = 0: two rows of one candidate (p0 -> p0 + 1, p0 + 2 -> p0 + 3); b = 1: the row p0 + 2 with p0, p0 + 1;  b >= 2: all four
-        const bool cov = b < 2 || !((p0 >> b) & 1);
-        const int64_t r = b == 0 ? p0 + 1 : ((p0 >> (b + 1)) << (b + 1)) + ((int64_t)1 << b);
-        const int64_t u = p0 >> (b + 1), mask = ((int64_t)1 << b) - 1;
-        // element of the lane's LAST candidate of the row (the smallest element index: elements run by descending p)
-        const int64_t plast = b == 0 ? p0 : b == 1 ? p0 + 1 : p0 + 3;
-        const int64_t e = (u << b) | (mask - (plast & mask));
-        const int64_t E = (T.tbase[b] << 8) + e;
+        if (b >= 8 && (bool)((Z0 >> b) & 1) != MIR) continue;       // (wave-uniform) no row of this level over the wave's columns
+        // the lane's row of this level and its candidates among z0 .. z0 + 3:
+        //   b = 0: two rows of one candidate each; b = 1: one row of two; b >= 2: all four
+        const int64_t mask = ((int64_t)1 << b) - 1;
+        const bool cov = b < 2 || (bool)((z0 >> b) & 1) == MIR;
+        const int64_t zr = (z0 >> (b + 1)) << (b + 1);              // z0 with the bits <= b cleared
+        const int64_t r = MIR ? zr : zr + ((int64_t)1 << b);        // (b = 0: the first of the lane's two rows)
+        const int64_t u = MIR ? (z0 >> (b + 1)) - 1 : z0 >> (b + 1);
+        // the lane's candidates k0, k0 + 1 (b = 1) or 0 .. 3 (b >= 2); element of the LAST one (the smallest index)
+        const int k0 = (b == 1 && MIR) ? 2 : 0;
+        const int64_t zlast = b == 1 ? z0 + k0 + 1 : z0 + 3;
+        const int64_t E = (T.tbase[b] << 8) + ((u << b) | (mask - (zlast & mask)));
         int32_t c[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
-        if (cov) {
+        if (b == 0) {
+            // single candidates: z0 + k (k = 0, 2; mirrored: 1, 3) -> rows r, r + 2; their elements are neighbours
+            const int kk = MIR ? 1 : 0;
+            const int64_t E0 = (T.tbase[0] << 8) + u;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int64_t rk = r + 2 * j, pk = p0 + kk + 2 * j;
+                if (rk >= 1 && rk <= n && pk >= 0 && (!MIR || u + j >= 0)) {
+                    const int64_t rw = PR(rk);
+                    opt[rw] = (int32_t)pk; nnopt[rw] = cnt[E0 + j]; if (HYP) nlopt[rw] = cnt2[E0 + j];
+                }
+            }
+            continue;
+        }
+        const bool rok = cov && r >= 1 && r <= n && u >= 0;
+        if (rok) {
             if (b >= 2) {
                 const int4 t = *reinterpret_cast<const int4 *>(cnt + E);
                 c[3] = t.x; c[2] = t.y; c[1] = t.z; c[0] = t.w;
                 if (HYP) { const int4 t2 = *reinterpret_cast<const int4 *>(cnt2 + E); d[3] = t2.x; d[2] = t2.y; d[1] = t2.z; d[0] = t2.w; }
-            } else if (b == 1) {
+            } else {
                 const int2 t = *reinterpret_cast<const int2 *>(cnt + E);
-                c[1] = t.x; c[0] = t.y;
-                if (HYP) { const int2 t2 = *reinterpret_cast<const int2 *>(cnt2 + E); d[1] = t2.x; d[0] = t2.y; }
-            } else {                                        // b = 0: elements of p0 and p0 + 2 are neighbours
-                const int2 t = *reinterpret_cast<const int2 *>(cnt + E);
-                c[0] = t.x; c[2] = t.y;
-                if (HYP) { const int2 t2 = *reinterpret_cast<const int2 *>(cnt2 + E); d[0] = t2.x; d[2] = t2.y; }
+                c[k0 + 1] = t.x; c[k0] = t.y;
+                if (HYP) { const int2 t2 = *reinterpret_cast<const int2 *>(cnt2 + E); d[k0 + 1] = t2.x; d[k0] = t2.y; }
             }
         }
-        if (b == 0) {                                       // single candidates: nothing to compare
-#pragma unroll
-            for (int k = 0; k < 4; k += 2) {
-                const int64_t rk = p0 + k + 1;
-                if (rk <= n) { const int64_t rw = PR(rk); opt[rw] = (int32_t)(p0 + k); nnopt[rw] = c[k]; if (HYP) nlopt[rw] = d[k]; }
-            }
-            continue;
-        }
-        const bool rok = cov && r <= n;
         const int32_t posr = pos[rok ? r : 0];
         Best<TC, HYP> x; best_clear(x);
-        const int nk = b == 1 ? 2 : 4;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (k >= nk || !rok) continue;
+            if (b == 1 && (k < k0 || k > k0 + 1)) continue;
+            if (!rok || p0 + k < 0) continue;               // (mirrored heads: a block may be cut off at column 0)
             Best<TC, HYP> cc; best_clear(cc);
             cc.v = cadd(wv[k], dm_apply(M, alpha, r - (p0 + k), (int64_t)(posr - pv[k]), (int64_t)c[k], (int64_t)d[k]));
             cc.p = (int32_t)(p0 + k); cc.nn = c[k]; best_set_nl(cc, d[k]);
@@ -2145,12 +2153,14 @@ __global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restr
         }
         if ((lane & (lpr - 1)) == 0 && rok) {
             if (b <= 8) {
-                const int64_t rw = (int64_t)b * n1 + PR(r);
-                opt[rw] = x.p; nnopt[rw] = x.nn;
-                if (HYP) nlopt[rw] = best_nl(x);
+                if (x.p >= 0) {
+                    const int64_t rw = (int64_t)b * n1 + PR(r);
+                    opt[rw] = x.p; nnopt[rw] = x.nn;
+                    if (HYP) nlopt[rw] = best_nl(x);
+                }
             } else {
-                // lane 0: the wave's smallest element of the row is that of its last column (P0 + 255)
-                const int64_t el = (u << b) | (mask - ((P0 + LT - 1) & mask));
+                // lane 0: the wave's smallest element of the row is that of its last column
+                const int64_t el = (u << b) | (mask - ((Z0 + LT - 1) & mask));
                 part[T.tbase[b] + (el >> 8) - T.tbase[9]] = x;
             }
         }
@@ -2559,10 +2569,10 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             const bool colmajor = !(g_opt_dbg & 262144);       // (dbg 262144: the row-major kernel k_ra_layer)
             const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
             if (colmajor && hyp)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
                                    Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, (int64_t)0, cdiv(n, LT));
             else if (colmajor)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
                                    Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p), (int64_t)0, cdiv(n, LT));
             if (hyp) {
                 if (!colmajor)
@@ -2595,13 +2605,13 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             ProfScope ps(PROF_RA, s, 60.0 * (double)(tile1 - tile0) * LT);
             const unsigned cgrid = (unsigned)std::max<int64_t>(1, cdiv(tile1 - tile0, 4));
             if (hyp) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
                                    Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, tile0, tile1);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
             } else {
                 auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
                                    Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa, tile0, tile1);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   pa, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
@@ -2621,14 +2631,25 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                         T3.thi[b] = std::min<int64_t>(T3.tbase[b + 1], T3.tbase[b] + cdiv(std::max<int64_t>(u_hi, 0) << b, LT));
                         elems += (double)std::max<int64_t>(0, T3.thi[b] - T3.tlo[b]) * LT;
                     }
-                    ProfScope ps2(PROF_RA, s, 16.0 * elems);
+                    // column-major like the standard heads (z = p + w + 1: the blocks of the rows r_lo .. r_hi lie in [r_lo, r_hi + 2^s)); the
+                    // row-major kernel (dbg 8388608) reads 16 B per (candidate, level) instead of 4
+                    const bool mcols = !(g_opt_dbg & 8388608);
+                    const int64_t zt0 = r_lo / LT, zt1 = cdiv(std::min<int64_t>(n + G.w + 1, r_hi + ((int64_t)1 << G.s) + 1), LT);
+                    ProfScope ps2(PROF_RA, s, mcols ? 80.0 * (double)(zt1 - zt0) * LT : 16.0 * elems);
+                    const unsigned mgrid = (unsigned)std::max<int64_t>(1, cdiv(zt1 - zt0, 4));
                     if (hyp) {
+                        if (mcols) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, true>), dim3(mgrid), dim3(256), 0, s, T3, Wk.mir_c.p, Wk.mir_c2.p, A->pos32.p, W, M, alpha,
+                                                      Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p, zt0, zt1);
+                        else
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p, Wk.mir_c2.p,
                                            A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p);
                         if (Wk.mir_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(Wk.mir_nrow, 4)), dim3(256), 0, s, T3, Wk.mir_nrow,
                                                                 Wk.mir_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
                     } else {
                         auto *pm = reinterpret_cast<Best<TC, false> *>(Wk.mir_part.p);
+                        if (mcols) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, true>), dim3(mgrid), dim3(256), 0, s, T3, Wk.mir_c.p, (const int32_t *)nullptr, A->pos32.p, W, M,
+                                                      alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm, zt0, zt1);
+                        else
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, false>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p,
                                            (const int32_t *)nullptr, A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm);
                         if (Wk.mir_nrow > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(Wk.mir_nrow, 4)), dim3(256), 0, s, T3, Wk.mir_nrow,

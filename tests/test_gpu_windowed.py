@@ -60,7 +60,7 @@ def test_constrained_tables_bit_exact(hip, orc, mi):
 
 
 OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
-           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 1048576}, {"dbg": 2097152}, {"ra_cache": 0}, {"force_max": 1000000}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048}]
+           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 1048576}, {"dbg": 2097152}, {"dbg": 8388608}, {"ra_cache": 0}, {"force_max": 1000000}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048}]
 DEFAULTS = {"ra_cache": 1, "nospec": 0, "gap_tau": 6, "gap_min": 64, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "short_t": 8, "short_e": 64, "own_min": 64}
 
 
@@ -141,7 +141,7 @@ def test_round_a_caches_change_no_table_cell_at_3e5(hip):
         mm = mdl.marshal()
         rc0, lo0, hi0, p0, c0 = hip.dynamic_tables_constrained(A, K, mm, w)
         assert rc0 == 0, hip.last_error()
-        for dbg in (1048576, 2097152):
+        for dbg in (1048576, 2097152, 8388608):
             hip.set_option("dbg", dbg)
             try:
                 rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w)
