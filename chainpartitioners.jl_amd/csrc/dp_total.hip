@@ -284,11 +284,22 @@ __global__ void __launch_bounds__(64 * WPB) k_rpass_wave(int tau, int nbits, int
     // (Tried: four 16-byte loads per lane and 1024 entries per iteration -- 101 VGPRs, occupancy 4, 18 % slower.)
     // eight coalesced loads per step, the next step's issued before this one's are counted: 4 KB in flight per wave
     int32_t a[8], nx[8];
+    struct __attribute__((packed, aligned(4))) V4 { int32_t x, y, z, w; };      // (16-byte loads, dword-aligned: a quarter of the memory instructions)
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const int64_t q = q0 + lane + 64 * k; a[k] = q < q1 ? prev[q] : NEVER; }
+    for (int k = 0; k < 2; k++) {
+        const int64_t q = q0 + 4 * lane + 256 * k;
+        V4 t = {NEVER, NEVER, NEVER, NEVER};
+        if (q < q1) t = *reinterpret_cast<const V4 *>(prev + q);
+        a[4 * k] = t.x; a[4 * k + 1] = q + 1 < q1 ? t.y : NEVER; a[4 * k + 2] = q + 2 < q1 ? t.z : NEVER; a[4 * k + 3] = q + 3 < q1 ? t.w : NEVER;
+    }
     for (int64_t qb = q0; qb < q1; qb += 512) {                // (a wave-uniform trip count keeps the counters on the scalar unit)
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const int64_t q = qb + 512 + lane + 64 * k; nx[k] = q < q1 ? prev[q] : NEVER; }
+        for (int k = 0; k < 2; k++) {
+            const int64_t q = qb + 512 + 4 * lane + 256 * k;
+            V4 t = {NEVER, NEVER, NEVER, NEVER};
+            if (q < q1) t = *reinterpret_cast<const V4 *>(prev + q);
+            nx[4 * k] = t.x; nx[4 * k + 1] = q + 1 < q1 ? t.y : NEVER; nx[4 * k + 2] = q + 2 < q1 ? t.z : NEVER; nx[4 * k + 3] = q + 3 < q1 ? t.w : NEVER;
+        }
         for (uint32_t rem = act; rem; rem &= rem - 1) {
             const int b = __ffs(rem) - 1;
             const int32_t t = __builtin_amdgcn_readlane(tv, b);
