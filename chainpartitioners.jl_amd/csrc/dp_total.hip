@@ -281,8 +281,9 @@ __global__ void __launch_bounds__(64 * WPB) k_rpass_wave(int tau, int nbits, int
     int32_t acc = 0;
     const int64_t q0 = pos[c0], q1 = pos[c1];
     const int32_t NEVER = ge ? INT32_MIN : INT32_MAX;          // a link value that is never counted
-    // (Tried: four 16-byte loads per lane and 1024 entries per iteration -- 101 VGPRs, occupancy 4, 18 % slower.)
-    // eight coalesced loads per step, the next step's issued before this one's are counted: 4 KB in flight per wave
+    // 512 entries per step as two 16-byte loads per lane, the next step's issued before this one's are counted: 4 KB in flight per
+    // wave at 39 VGPRs.  (With scalar-register arrays for thresholds and counts, four 16-byte loads per lane and 1024 entries per
+    // step needed 101 VGPRs -- occupancy 4, 18 % slower.)
     int32_t a[8], nx[8];
     struct __attribute__((packed, aligned(4))) V4 { int32_t x, y, z, w; };      // (16-byte loads, dword-aligned: a quarter of the memory instructions)
 #pragma unroll
