@@ -1983,7 +1983,13 @@ __global__ void __launch_bounds__(256) k_ra_colcount(RATab T, const int32_t *__r
     int32_t c = 0, c2 = 0;
     if (ok) {
         int32_t rr = (int32_t)r;
-        for (int32_t q = pos[p], q1 = pos[p + 1]; q < q1; q++) c += (next[q] >= rr);
+        for (int32_t q = pos[p], q1 = pos[p + 1]; q < q1; q += 8) {        // eight loads in flight (one at a time: a memory latency per entry)
+            int32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = q + k < q1 ? next[q + k] : INT32_MIN;
+#pragma unroll
+            for (int k = 0; k < 8; k++) c += (v[k] >= rr);
+        }
         if (d2) for (int32_t q = fpos[p], q1 = fpos[p + 1]; q < q1; q++) c2 += (flast[q] < rr);
     }
     d[E] = c;
