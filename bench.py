@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- benchmarks of the partition_stripe / pack_stripe hot path on MI355X.
 
-  python bench.py [--config C] --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py [--config C] --gpus N --steps K --warmup W
+
+N > 1: either under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / WORLD_SIZE in the
+environment) or plain `python bench.py --gpus N`, which starts the N ranks itself from a parent that never touches a GPU
+(launch_ranks, before `import torch`).  WORLD_SIZE != --gpus is an error.  The line carries `value` = independent partitions, one
+per GPU (weak scaling, no data-path collective) and `extras.tiled` = ONE partition with its DP rows tiled over the GPUs and an
+RCCL all_gather per layer (strong scaling); `--mode tiled` makes the row-tiled partition `value` itself.
 
 Configs (every matrix comes from the seeded SplitMix64 generator tests/synth.py, base seed 0xDEADBEEF +
 config index; one "step" = one full partition call INCLUDING oracle construction, colptr / rowval already resident in HBM --
@@ -17,8 +23,9 @@ what the reference's `@benchmarkable partition_stripe($A,$K,$f)` times, test/run
   2           BisectCostBottleneckSplitter(AffineWorkModel(0,10,1) / AffineConnectivityModel(0,10,1,100), 0.01), n = 10^6, K = 32.
   4           ConvexTotalChunker / DynamicTotalChunker(ConstrainedCost(ColumnBlockComponentCostModel{Int}(3, w->1+w),
               VertexCount(), 8)) on banded n = 5*10^6 (test/runbenchmarks.jl:21,31-33), the oracle timed beside it at full size.
-  5shape      DynamicTotalSplitter(AffineHyperedgeCutModel(0,0,0,0,1)) on n = 5*10^7, nnz = 5*10^8 on ONE GPU (config 5 is the
-              8-GPU row-tiled run of the same shape: --config 5shape --mode tiled under torch.distributed.run).
+  5           DynamicTotalSplitter(AffineHyperedgeCutModel(0,0,0,0,1)), K = 256, on n = 5*10^7, nnz = 5*10^8 (BASELINE config 5;
+              `--gpus 8 --mode tiled` is its 8-GPU row-tiled form, `--gpus 1` the same partition on one GPU: ptr is 4 B x K x n = 51 GB).
+  5shape      the same with K = 64 (round-2 comparisons).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     : the dominant kernel, HIP-event timed inside the timed region, against the 8 TB/s HBM peak
@@ -29,11 +36,56 @@ host-to-device copy of the pattern, and the second CPU baseline (the oracle's Co
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+# ------------------------------------------------------------------------------------------------ N > 1: the launcher
+def launch_ranks(gpus, argv):
+    """`python bench.py --gpus N` with no RANK in the environment: start N worker processes, one per device, from THIS process,
+    which has touched no GPU (it runs before `import torch`; the workers are children, nothing is re-exec'ed).  Rank 0's stdout
+    is ours, so its ONE JSON line is the launcher's line.  Any worker that fails takes the group down and the launcher fails."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                sys.stderr.write("bench.py launcher: rank %d exited with %d; stopping the other ranks\n" % (procs.index(p), c))
+                for q in alive:
+                    q.terminate()                     # (the exact children started above)
+    return rc
+
+
+def _early_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "RANK" not in os.environ and _early_gpus(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(_early_gpus(sys.argv[1:]), sys.argv[1:]))
 
 import numpy as np
 import torch
@@ -84,36 +136,53 @@ def timed(f, reps):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines (oracle, 1 core)
-def cpu_fit_quadratic(make_method, K, mean_deg, seed, sizes=(4000, 8000, 16000), budget_s=25.0, per_k=True):
-    """the literal O(n^2)-per-layer sweeps cannot run at bench size: time them at small n on the same generator, fit
-    t = a * [K *] n^2 and extrapolate"""
+def cpu_fit_quadratic(make_method, K, mean_deg, seed, sizes=(2000, 4000, 8000), repeats=3, budget_s=60.0, per_k=True):
+    """the literal O(n^2)-per-layer sweeps cannot run at bench size: time them at three sizes on the same generator (min of
+    `repeats` runs each; the sizes are the largest three that fit the budget: n = 4*10^4 alone would take four minutes),
+    fit t = a * [K *] n^2 by least squares through the origin and extrapolate.  -> (a, [(n, seconds, a_n)])"""
     cp = cpamd.load()
     orc = oracle_backend()
     samples, used = [], 0.0
     for n in sizes:
-        est = samples[-1][1] * 4 if samples else 0.0
-        if used + est > budget_s:
+        est = samples[-1][1] * 4 * repeats if samples else 0.0
+        if samples and used + est > budget_s:
             break
         _, _, colptr, rowval = synth.suitesparse_shaped_np(n, mean_deg, seed, nnz=int(n * mean_deg))
         A = cp.SparseMatrixCSC(n, n, colptr, rowval)
-        t0 = time.perf_counter()
-        cp.partition_stripe(A, K, make_method(cp, n), backend=orc)
-        dt = time.perf_counter() - t0
-        samples.append((n, dt)); used += dt
-    a = float(np.mean([dt / ((K if per_k else 1) * n * n) for n, dt in samples]))
-    return a, samples
+        best = None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            cp.partition_stripe(A, K, make_method(cp, n), backend=orc)
+            dt = time.perf_counter() - t0
+            used += dt
+            best = dt if best is None else min(best, dt)
+        samples.append((n, best, best / ((K if per_k else 1) * float(n) * n)))
+    x = np.array([(K if per_k else 1) * float(n) * n for n, _, _ in samples])
+    y = np.array([t for _, t, _ in samples])
+    return float((x * y).sum() / (x * x).sum()), samples
 
 
-def cpu_convex_splitter(K, mean_deg, seed, n=100_000):
+def cpu_convex_splitter(K, mean_deg, seed, hip, n=100_000):
     """SURVEY 8(d) second baseline: the oracle's ConvexTotalSplitter -- the reference's own fastest exact-value method for this
-    cost -- timed directly at the largest n that fits the budget"""
+    cost -- timed directly at the largest n that fits the budget, and the GPU's DynamicTotalSplitter on the SAME matrix beside it
+    (pattern resident, oracle structures rebuilt, like `value`) so that the ratio is taken at one size.
+    -> (n, oracle seconds, gpu seconds, same total value)"""
     cp = cpamd.load()
     orc = oracle_backend()
     _, _, colptr, rowval = synth.suitesparse_shaped_np(n, mean_deg, seed, nnz=int(n * mean_deg))
     A = cp.SparseMatrixCSC(n, n, colptr, rowval)
+    mdl = cp.AffineConnectivityModel(0, 0, 0, 1)
     t0 = time.perf_counter()
-    cp.partition_stripe(A, K, cp.ConvexTotalSplitter(cp.AffineConnectivityModel(0, 0, 0, 1)), backend=orc)
-    return n, time.perf_counter() - t0
+    P = cp.partition_stripe(A, K, cp.ConvexTotalSplitter(mdl), backend=orc)
+    tc = time.perf_counter() - t0
+    G = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)      # (uploads the pattern, warms the handle)
+
+    def gpu():
+        hip.reset_cache(A)
+        cp.partition_stripe(A, K, cp.DynamicTotalSplitter(mdl), backend=hip)
+    tg = min(timed(gpu, 1) for _ in range(3))
+    same = cp.total_value(A, P, mdl, backend=hip) == cp.total_value(A, G, mdl, backend=hip)
+    return n, tc, tg, bool(same)
 
 
 # ------------------------------------------------------------------------------------------------ the DP configs on one matrix
@@ -125,10 +194,10 @@ class DpBench:
         from chainpartitioners_jl_amd import _lib
         self.hip = _lib.HipBackend(device=dev.index)
         self.args, self.cfg, self.dev, self.tiled = args, cfg, dev, tiled
-        big = cfg == "5shape"
+        big = cfg in ("5", "5shape")
         self.n = args.n or (50_000_000 if big else 10_000_000)
-        N = args.nnz or (500_000_000 if big else 100_000_000)
-        self.K = args.parts or 64
+        N = args.nnz or (10 * self.n if args.n else (500_000_000 if big else 100_000_000))
+        self.K = args.parts or (256 if cfg == "5" else 64)
         seed = SEED + (5 if big else 3) - 1 + (0 if tiled else 1000 * rank)      # config index; independent partitions: one matrix per rank
         self.colptr, self.rowval = gen_suitesparse_shaped(self.n, N, seed, dev)
         self.N = int(self.rowval.numel())
@@ -192,6 +261,81 @@ class DpBench:
         return info
 
 
+def time_region(B, steps, dist, dev):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; the MAX over the ranks"""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        B.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
+
+
+def tiled_extra(args, cfg, dev, rank, world, dist, out, expect_s):
+    """N > 1, default mode: after the independent partitions (`value`, weak scaling), ONE partition of the same shape with its
+    DP rows tiled over the ranks (strong scaling, chainpartitioners.jl_amd/distributed.py) goes into `extras.tiled`.  The
+    row-tiled exchange has met one RCCL rank only before the driver's scaling run, so a watchdog turns a stuck or failed run
+    into an `error` entry: the weak-scaling line is printed regardless."""
+    steps = max(1, min(args.steps, 3))
+    limit = 180.0 + 8.0 * (steps + 1) * expect_s
+    res = {"n_gpus": world, "scaling": "strong", "steps": steps, "warmup": 1, "mode": "one partition, DP rows tiled over the GPUs, one all_gather per layer"}
+    done = threading.Event()
+
+    def bail(msg):
+        if rank == 0:
+            res["error"] = msg
+            out["extras"]["tiled"] = res
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    def watchdog():
+        if not done.wait(limit):
+            bail("no answer from the row-tiled run within %.0f s" % limit)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        B = DpBench(args, cfg, dev, rank, world, True)
+        B.step()
+        dt = time_region(B, steps, dist, dev)
+        res.update({"ms_per_step": dt / steps * 1e3, "value": steps / dt, "unit": "partitions/s", "check": B.check()})
+        B.hip.csr_destroy(B.h)
+    except Exception as e:                               # (the other ranks are waiting in a collective: their watchdogs end them)
+        bail("row-tiled run failed on rank %d: %r" % (rank, e))
+    done.set()
+    if rank == 0:
+        out["extras"]["tiled"] = res
+
+
+def dp_cpu_baseline(B, cfg, sizes):
+    """the oracle's literal DP of the same method on one host core, fitted at small n and extrapolated"""
+    n, N, K = B.n, B.N, B.K
+    Kfit = min(K, 64)                    # (the law is linear in K: a is fitted with at most 64 parts, stated in `sample`)
+    avg_deg = N / n
+    if cfg == "constrained":
+        mk = lambda cp, nn: cp.DynamicTotalSplitter(cp.ConstrainedCost(B.mdl, cp.VertexCount(), -(-3 * nn // (2 * Kfit))))
+        a, samples = cpu_fit_quadratic(mk, Kfit, avg_deg, SEED + 2, sizes=sizes, per_k=False)
+        t_full = a * float(n) * float(n)
+        law = ("t = a*n^2 with a=%.3e s (layer k scans its window of up to (n+1) - (K-k) w .. k w rows, each over at most w = ceil(1.5 n / K) "
+               "candidates: Theta(n w K / 2) = Theta(n^2) steps whatever K)" % a)
+    else:
+        mk = (lambda cp, nn: cp.DynamicBottleneckSplitter(B.mdl)) if B.combine else (lambda cp, nn: cp.DynamicTotalSplitter(B.mdl))
+        a, samples = cpu_fit_quadratic(mk, Kfit, avg_deg, SEED + 2, sizes=sizes)
+        t_full = a * K * float(n) * float(n)
+        law = "t = a*K*n^2 with a=%.3e s" % a
+    return {"value": 1.0 / t_full, "unit": "partitions/s", "cores": 1, "kind": "port",
+            "sample": "literal restatement of %s timed at n=%s (K=%d, same generator, min of 3 runs each), least-squares %s, extrapolated to n=%d, K=%d"
+                      % (B.method_name(), [s[0] for s in samples], Kfit, law, n, K),
+            "sample_seconds": [s[1] for s in samples], "a_per_size": [s[2] for s in samples], "host_cores": os.cpu_count()}
+
+
 def run_dp(args, cfg, dev, rank, world, dist):
     tiled = args.mode == "tiled" and dist is not None
     B = DpBench(args, cfg, dev, rank, world, tiled)
@@ -213,29 +357,18 @@ def run_dp(args, cfg, dev, rank, world, dist):
     dom, kname = max(cands, key=lambda kv: prof_all.get(kv[0], {"ms": 0.0})["ms"])
     hip.prof_reset()
     assert hip.set_option("prof_only", slots.index(dom)) == 0
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        B.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time_region(B, args.steps, dist, dev)
+    B.last_step_s = dt / args.steps
     hip.prof_enable(False)
     hip.set_option("prof_only", -1)
     prof = hip.prof_get()
     spl_t = torch.from_numpy(B.spl.copy()).to(dev)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         gathered = [torch.empty_like(spl_t) for _ in range(world)]      # the K+1-entry split vectors of all ranks: one RCCL all_gather
         dist.all_gather(gathered, spl_t)
     info = B.check()
     if rank != 0:
-        return None
+        return None, B
     ms_per_step = dt / args.steps * 1e3
     value = (1 if tiled else world) * args.steps / dt
     ex = prof[dom]
@@ -243,10 +376,16 @@ def run_dp(args, cfg, dev, rank, world, dist):
     avg_ms = ex["ms"] / max(ex["launches"], 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     b_alg = 8.0 * (n + 1 + N) + K * (n + 1) * 24.0 + 8.0 * (K + 1)      # SURVEY.md 8(d) whole-partition bytes
+    # HBM bytes per launch from the PMC counters: a STORED measurement (separate --pmc passes cannot run inside this process,
+    # tools/pmc_lpass.sh), so it is printed with its source and the commit it was taken at -- null when none exists for this kernel
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % kname)
-    if cfg == "3" and os.path.exists(pmc_path) and (n, N) == (10_000_000, 100_000_000):
-        traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch_corrected")
+    for rnd in ("r03", "r02"):
+        pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, kname))
+        if cfg == "3" and os.path.exists(pmc_path) and (n, N) == (10_000_000, 100_000_000):
+            pm = json.load(open(pmc_path))
+            traffic = {"bytes": pm.get("traffic_bytes_per_launch_corrected"), "bytes_raw": pm.get("traffic_bytes_per_launch_raw"),
+                       "stored": True, "source": "profiles/%s_pmc_%s.json" % (rnd, kname), "measured_at": pm.get("measured_at", "round 2 (commit 5d697b7)")}
+            break
     out = {
         "metric": "partitions/sec, %s, K=%d" % (B.method_name(), K),
         "value": value, "unit": "partitions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -285,22 +424,8 @@ def run_dp(args, cfg, dev, rank, world, dist):
                 B.cp.partition_stripe(A_host, K, meth, backend=hip)
             out["extras"]["ms_per_step_with_h2d"] = timed(with_h2d, 1) * 1e3
             del A_host, hc, hr
-    if not args.no_cpu_baseline:
-        avg_deg = N / n
-        if cfg in ("3", "5shape", "bottleneck"):
-            mk = (lambda cp, nn: cp.DynamicBottleneckSplitter(B.mdl)) if B.combine else (lambda cp, nn: cp.DynamicTotalSplitter(B.mdl))
-            a, samples = cpu_fit_quadratic(mk, K, avg_deg, SEED + 2)
-            t_full = a * K * float(n) * float(n)
-            law = "t = a*K*n^2 with a=%.3e s" % a
-        else:
-            mk = lambda cp, nn: cp.DynamicTotalSplitter(cp.ConstrainedCost(B.mdl, cp.VertexCount(), -(-3 * nn // (2 * K))))
-            a, samples = cpu_fit_quadratic(mk, K, avg_deg, SEED + 2, per_k=False)
-            t_full = a * float(n) * float(n)
-            law = "t = a*n^2 (the windows make the work independent of K) with a=%.3e s" % a
-        out["cpu_baseline"] = {"value": 1.0 / t_full, "unit": "partitions/s", "cores": 1, "kind": "port",
-                               "sample": "literal restatement of %s timed at n=%s (K=%d, same generator), %s extrapolated to n=%d"
-                                         % (B.method_name(), [s[0] for s in samples], K, law, n),
-                               "sample_seconds": [s[1] for s in samples], "host_cores": os.cpu_count()}
+    if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only)
+        out["cpu_baseline"] = dp_cpu_baseline(B, cfg, sizes=getattr(args, "cpu_sizes", (2000, 4000, 8000)))
     return out, B
 
 
@@ -413,9 +538,35 @@ def run_cfg4(args, dev):
     return out
 
 
+def dry_run(args, rank, world, dist):
+    """--dry-run (launcher / protocol rehearsal on a box without GPUs, tests/test_bench_launcher.py): the rendezvous, the
+    barrier-bracketed timed region, the MAX over ranks and the split-vector all_gather of the real run over gloo, with a
+    stand-in step that computes nothing.  `value` is null: this is not a measurement."""
+    def step():
+        time.sleep(0.01 * (1 + rank))
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    me = torch.tensor([rank, os.getpid()], dtype=torch.int64)
+    seen = [torch.empty_like(me) for _ in range(world)]
+    dist.all_gather(seen, me)
+    if rank != 0:
+        return None
+    return {"metric": "dry run of the N-rank bench protocol (no GPU work)", "value": None, "unit": "partitions/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tmax.item()) / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "none", "dry_run": True,
+            "config": {"workload": "dry run"}, "ranks_seen": [int(t[0]) for t in seen], "pids": [int(t[1]) for t in seen]}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="3", choices=["3", "constrained", "bottleneck", "2", "4", "5shape"])
+    ap.add_argument("--config", default="3", choices=["3", "constrained", "bottleneck", "2", "4", "5", "5shape"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -423,17 +574,34 @@ def main():
     ap.add_argument("--nnz", type=int, default=0)
     ap.add_argument("--parts", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="config 3: skip the short runs of the other configs")
+    ap.add_argument("--no-extras", action="store_true", help="config 3: skip the short runs of the other configs; N > 1: skip extras.tiled")
     ap.add_argument("--opt", action="append", default=[], help="library tunable name=value (cp_set_option), e.g. short_t=4")
     ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
-                    help="N>1: 'independent' = one partition per GPU (weak scaling, default); 'tiled' = ONE partition whose DP rows "
-                         "are tiled over the GPUs with an RCCL all_gather per layer (strong scaling)")
+                    help="N>1: 'independent' = one partition per GPU (weak scaling, `value`) followed by ONE row-tiled partition in "
+                         "extras.tiled (strong scaling); 'tiled' = `value` itself is the row-tiled partition (RCCL all_gather per layer)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + collectives without GPU work (tests)")
+    ap.add_argument("--emit-spl", action="store_true", help="put rank 0's split vector into check.spl (parity tests at small n)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: launch with `python bench.py --gpus N` (self-launching) or "
+                 "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.backend == "gloo" and not args.dry_run:
+        sys.exit("bench.py: the gloo backend exists for --dry-run only; measurements run over RCCL")
     dist = None
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        out = dry_run(args, rank, world, dist)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        dist.destroy_process_group()
+        return
     if world > 1 or args.mode == "tiled":
         # (--mode tiled on one GPU: a one-rank RCCL group, so that the row-tiled driver and its collectives can be timed on a one-GPU box)
         import torch.distributed as dist
@@ -451,30 +619,39 @@ def main():
     elif args.config == "4":
         out = run_cfg4(args, dev) if rank == 0 else None
     else:
-        res = run_dp(args, args.config, dev, rank, world, dist)
-        out = None
-        if res is not None:
-            out, B = res
-            if args.config == "3" and world == 1 and not args.no_extras:
-                # driver-visible lines of the other single-GPU configs: short runs on the same resident matrix
-                other = {}
-                sub = argparse.Namespace(**vars(args)); sub.steps = 2; sub.warmup = 1; sub.no_cpu_baseline = True
-                B.hip.csr_destroy(B.h); del B
+        out, B = run_dp(args, args.config, dev, rank, world, dist)
+        if out is not None and args.emit_spl:
+            out["check"]["spl"] = [int(x) for x in B.spl]
+        if world > 1 and args.mode == "independent" and not args.no_extras:
+            expect_s = float(B.last_step_s)
+            B.hip.csr_destroy(B.h); del B
+            torch.cuda.empty_cache()
+            tiled_extra(args, args.config, dev, rank, world, dist, out, expect_s)
+        elif out is not None and args.config == "3" and world == 1 and not args.no_extras:
+            # driver-visible lines of the other single-GPU configs: short runs on the same resident matrix
+            other = {}
+            sub = argparse.Namespace(**vars(args)); sub.steps = 2; sub.warmup = 1; sub.cpu_sizes = (2000, 4000)
+            B.hip.csr_destroy(B.h); del B
+            torch.cuda.empty_cache()
+            for c in ("constrained", "bottleneck"):
+                o, b2 = run_dp(sub, c, dev, 0, 1, None)
+                other[c] = {"metric": o["metric"], "ms_per_step": o["ms_per_step"], "value": o["value"], "check": o["check"],
+                            "dominant_kernel": o["roofline"]["kernel"], "roofline_frac": o["roofline"]["frac"], "kernels_ms_per_step": o["kernels_ms_per_step"]}
+                if "cpu_baseline" in o:
+                    other[c]["cpu_baseline"] = o["cpu_baseline"]
+                b2.hip.csr_destroy(b2.h); del b2
                 torch.cuda.empty_cache()
-                for c in ("constrained", "bottleneck"):
-                    o, b2 = run_dp(sub, c, dev, 0, 1, None)
-                    other[c] = {"metric": o["metric"], "ms_per_step": o["ms_per_step"], "value": o["value"], "check": o["check"],
-                                "dominant_kernel": o["roofline"]["kernel"], "roofline_frac": o["roofline"]["frac"], "kernels_ms_per_step": o["kernels_ms_per_step"]}
-                    b2.hip.csr_destroy(b2.h); del b2
-                    torch.cuda.empty_cache()
-                sub.n = 0; sub.parts = 0
-                other["2"] = run_cfg2(sub, dev, brief=True)
-                out["extras"]["other_configs"] = other
-                if not args.no_cpu_baseline:
-                    nn, tc = cpu_convex_splitter(out["config"]["K"], out["config"]["nnz"] / out["config"]["n"], SEED + 2)
-                    out["extras"]["cpu_baseline_2"] = {"method": "ConvexTotalSplitter(AffineConnectivityModel(0,0,0,1)) (the reference's fastest exact-value method for this cost), oracle, 1 core",
-                                                       "n": nn, "K": out["config"]["K"], "seconds": tc,
-                                                       "note": "timed directly at n=%d (same generator); super-linear in n (wavelet queries leave cache): n=1e7 is out of reach" % nn}
+            sub.n = 0; sub.parts = 0
+            other["2"] = run_cfg2(sub, dev, brief=True)
+            out["extras"]["other_configs"] = other
+            if not args.no_cpu_baseline:
+                from chainpartitioners_jl_amd import _lib
+                nn, tc, tg, same = cpu_convex_splitter(out["config"]["K"], out["config"]["nnz"] / out["config"]["n"], SEED + 2, _lib.HipBackend(device=dev.index))
+                out["extras"]["cpu_baseline_2"] = {"method": "ConvexTotalSplitter(AffineConnectivityModel(0,0,0,1)) (the reference's fastest exact-value method for this cost), oracle, 1 core",
+                                                   "n": nn, "K": out["config"]["K"], "seconds": tc,
+                                                   "gpu_seconds_same_matrix": tg, "gpu_method": "DynamicTotalSplitter, all K layers, structures rebuilt",
+                                                   "same_total_value": same,
+                                                   "note": "timed directly at n=%d (same generator); super-linear in n (wavelet queries leave cache): n=1e7 is out of reach" % nn}
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:

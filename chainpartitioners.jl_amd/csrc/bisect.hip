@@ -327,7 +327,7 @@ extern "C" int32_t cp_partition_bisect_cost_pi(cp_csr_t A, int64_t K, const cp_m
         if (rc != CP_OK) return rc;
         if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, Pi, lf, hf, eps, flip, spl_out);
         return run_bisect<double>(A, K, model, Pi, lf, hf, eps, flip, spl_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 extern "C" int32_t cp_partition_bisect_cost(cp_csr_t A, int64_t K, const cp_model_t *model, double eps, int32_t flip, int64_t *spl_out)
@@ -347,7 +347,7 @@ extern "C" int32_t cp_partition_bisect_index_pi(cp_csr_t A, int64_t K, const cp_
         if (rc != CP_OK) return rc;
         if (model->dtype == CP_I64) return run_bisect<int64_t>(A, K, model, Pi, lf, hf, 0.0, flip, spl_out, true);
         return run_bisect<double>(A, K, model, Pi, lf, hf, 0.0, flip, spl_out, true);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 extern "C" int32_t cp_partition_bisect_index(cp_csr_t A, int64_t K, const cp_model_t *model, int32_t flip, int64_t *spl_out)

@@ -119,14 +119,20 @@ static bool fast_total_ok(const cp_model_t *m, int64_t n, int64_t N, int64_t K)
 
 // is the valley search of dp_bottleneck.hip exact for this model?  Needs a cost that grows with its part: every beta >= 0
 // (hyperedge cut: cost = d*b_cut + l*(b_self - b_cut) with d, l growing, so b_cut >= 0 and b_self >= b_cut).  alpha, alpha[k]
-// and the element type are free (no sums are reassociated: a max of two values).
-static bool fast_bottleneck_ok(const cp_model_t *m)
+// are free.  Element type: Work / Connectivity costs are sums of terms that are EACH monotone in the part (counts times a
+// non-negative beta) and IEEE addition is monotone, so non-integral Float64 parameters keep the valley.  The hyperedge cost is
+// evaluated as fl(l*b_self) + fl((d-l)*b_cut) (HyperedgeCutCosts.jl:21) and its (d - l) term is NOT monotone in the part:
+// with non-integral betas the rounded value can rise by an ulp while the part shrinks and the valley breaks (35 of 360 layers
+// differed from the literal sweep for (0,0,0,.1,.1), (0,0,0,.7,.1), (.3,.1,0,.3,.3)).  Those go to the general sweep; with
+// integer-valued parameters and totals below 2^53 every product and sum is exact and the real-number argument holds.
+static bool fast_bottleneck_ok(const cp_model_t *m, int64_t n, int64_t N, int64_t K)
 {
     auto P = [&](int i) { return m->dtype == CP_I64 ? (double)m->p_i64[i] : m->p_f64[i]; };
     if (!(P(CP_P_VERTEX) >= 0 && P(CP_P_PIN) >= 0)) return false;
     if (m->kind == CP_MODEL_WORK) return true;
     if (m->kind == CP_MODEL_CONNECTIVITY) return P(CP_P_NET) >= 0;
-    if (m->kind == CP_MODEL_HYPEREDGE_CUT) return P(CP_P_CUT_NET) >= 0 && P(CP_P_SELF_NET) >= P(CP_P_CUT_NET);
+    if (m->kind == CP_MODEL_HYPEREDGE_CUT)
+        return P(CP_P_CUT_NET) >= 0 && P(CP_P_SELF_NET) >= P(CP_P_CUT_NET) && (m->dtype == CP_I64 || model_exact_on(m, n, N, K));
     return false;
 }
 
@@ -158,7 +164,7 @@ static int32_t run_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t orde
     int64_t n = A->n;
     bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
     bool fast = combine == CP_COMBINE_SUM && fast_total_ok(mdl, A->n, A->N, K) && !g_opt_force_brute;
-    const bool fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(mdl) && !g_opt_force_brute;
+    const bool fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(mdl, A->n, A->N, K) && !g_opt_force_brute;
     if (!fast && !fast_bn)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
@@ -390,7 +396,7 @@ static int32_t dp_begin(cp_csr_s *A, int64_t K, int32_t combine, int32_t order, 
     }
     D->need_self = model->kind == CP_MODEL_HYPEREDGE_CUT;
     D->fast = combine == CP_COMBINE_SUM && fast_total_ok(model, A->n, A->N, K) && !g_opt_force_brute;
-    D->fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(model) && !g_opt_force_brute;
+    D->fast_bn = combine == CP_COMBINE_MAX && fast_bottleneck_ok(model, A->n, A->N, K) && !g_opt_force_brute;
     if (!D->fast && !D->fast_bn)
         CP_REQUIRE(n <= g_opt_brute_max_n, CP_EUNSUPPORTED,
                    "model/objective outside the O(n log^2 n) class and n too large for the O(n^2) device sweep");
@@ -590,6 +596,20 @@ int32_t cp_set_stream(cp_csr_t A, void *hip_stream)
     A->stream = (hipStream_t)hip_stream;
     A->own_stream = false;
     return CP_OK;
+}
+
+int32_t cp_reset_stream(cp_csr_t A)
+{
+    if (!A) return CP_EINVAL;
+    return guarded([&]() -> int32_t {
+        if (A->stream || !A->own_stream) (void)hipStreamSynchronize(A->stream);      // (a borrowed stream may be the null stream)
+        if (A->own_stream) return CP_OK;
+        CP_HIP(hipSetDevice(A->device));
+        hipStream_t s = nullptr;
+        CP_HIP(hipStreamCreate(&s));
+        A->stream = s; A->own_stream = true;
+        return CP_OK;
+    });
 }
 
 int32_t cp_set_option(const char *name, int64_t value)

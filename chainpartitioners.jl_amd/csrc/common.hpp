@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 #include "../../include/chainpart.h"
@@ -33,6 +34,12 @@ struct HipFail { int32_t code; };
     do {                                                                                    \
         if (!(cond)) { cpk::set_error(msg); throw cpk::HipFail{code}; }                     \
     } while (0)
+
+// closes the try block of an extern "C" entry point: nothing may unwind through the C boundary (HIP / argument failures carry
+// their status code; a failed host allocation -- std::vector, new -- becomes CP_EHIP with a message)
+#define CP_CATCH_ALL                                                                         \
+    catch (const cpk::HipFail &e) { return e.code; }                                         \
+    catch (const std::bad_alloc &) { cpk::set_error("host allocation failed"); return CP_EHIP; }
 
 // ------------------------------------------------------------------ device buffers (RAII)
 template <typename T>

@@ -16,8 +16,10 @@
 // (self nets of the hyperedge-cut cost: rows bucketed by last / first column).  2 N link entries per layer in total.  The walk
 // of a chunk starts at its first row's crossing, found by a binary search over p with random-access counts from the wavelet
 // counter (the reference's NetCount / SelfNetCount query, SparseColorArrays.jl:121-125, 225-229).
-// Floating point: every term of the affine models is monotone in its count and IEEE addition is monotone, so the valley
-// holds for non-integral Float64 parameters as well; max() is exact.
+// Floating point: every term of the Work / Connectivity models is monotone in its count and IEEE addition is monotone, so the
+// valley holds for their non-integral Float64 parameters as well; max() is exact.  NOT so for the hyperedge-cut cost, whose
+// (d - l) * b_cut term shrinks while the part grows: its rounded sum can rise by an ulp against the real-number order, and
+// fast_bottleneck_ok (capi.hip) admits it only with integer-valued parameters (exact arithmetic) -- the rest runs dp_brute.hip.
 #include "csr.hpp"
 #include "model.hpp"
 #include "dp.hpp"

@@ -218,5 +218,5 @@ extern "C" int32_t cp_partition_lazy_bisect_cost(cp_csr_t A, int64_t K, const cp
         CP_REQUIRE(A->N < ((int64_t)1 << 31) - LZ_CH, CP_EUNSUPPORTED, "LazyBisectCost needs nnz < 2^31");
         if (model->dtype == CP_I64) return run_lazy<int64_t>(A, K, model, lf, hf, eps, spl_out);
         return run_lazy<double>(A, K, model, lf, hf, eps, spl_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }

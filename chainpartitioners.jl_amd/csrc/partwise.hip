@@ -96,5 +96,5 @@ extern "C" int32_t cp_partwise(cp_csr_t A, int64_t K, const int64_t *asg, int64_
         for (int64_t k = 0; k <= K; k++) pios_out[k] = h_pios[(size_t)k];
         *nprime_out = nprime;
         return CP_OK;
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }

@@ -1162,7 +1162,7 @@ int32_t cp_pack_dynamic(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t 
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_pack_dynamic<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
         return run_pack_dynamic<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_pack_convex(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64,
@@ -1173,7 +1173,7 @@ int32_t cp_pack_convex(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_pack_convex<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
         return run_pack_convex<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_partition_convex(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight,
@@ -1184,7 +1184,7 @@ int32_t cp_partition_convex(cp_csr_t A, int64_t K, const cp_model_t *model, cons
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_partition_convex<int64_t>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         return run_partition_convex<double>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_pack_concave(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight, int64_t wmax_i64,
@@ -1195,7 +1195,7 @@ int32_t cp_pack_concave(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t 
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_pack_concave<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
         return run_pack_concave<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_partition_concave(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, const cp_model_t *weight,
@@ -1206,7 +1206,7 @@ int32_t cp_partition_concave(cp_csr_t A, int64_t K, const cp_model_t *model, con
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_partition_concave<int64_t>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         return run_partition_concave<double>(A, K, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 }  // extern "C"

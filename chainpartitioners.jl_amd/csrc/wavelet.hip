@@ -222,7 +222,7 @@ __global__ void k_wsum_query(WsumDev<TW> S, const int64_t *__restrict__ colstart
 struct cp_wsum_s {
     int device = 0; hipStream_t stream = nullptr;
     int32_t dtype = 0;
-    int64_t Nk = 0, ncols = 0;
+    int64_t Nk = 0, ncols = 0, nrows = 0;
     cpk::WaveletHost wt;
     cpk::DBuf<uint64_t> Z, P0;              // 8-byte words (uint64 or double bit patterns)
     cpk::DBuf<int64_t> colstart;            // ncols + 1 (dominance over a CSR pattern); empty for rooks (column j starts at j - 1)
@@ -355,7 +355,7 @@ int32_t cp_count_build(cp_csr_t A, int32_t kind, int32_t hint, cp_count_t *out)
         prof_collect();
         *out = h;
         return CP_OK;
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_count_query(cp_count_t h, int64_t nq, const int64_t *a, const int64_t *b, int64_t *out)
@@ -384,7 +384,7 @@ int32_t cp_count_query(cp_count_t h, int64_t nq, const int64_t *a, const int64_t
         CP_HIP(hipStreamSynchronize(s));
         prof_collect();
         return CP_OK;
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_count_destroy(cp_count_t h)
@@ -400,7 +400,7 @@ static int32_t wsum_make(int device, int32_t dtype, int64_t nrows, int64_t ncols
     CP_REQUIRE(dtype == CP_I64 || dtype == CP_F64, CP_EINVAL, "weights are 8-byte integers (wrap-around sums) or Float64");
     CP_HIP(hipSetDevice(device));
     std::unique_ptr<cp_wsum_s> Wd(new cp_wsum_s());
-    Wd->device = device; Wd->dtype = dtype; Wd->Nk = Nk; Wd->ncols = ncols;
+    Wd->device = device; Wd->dtype = dtype; Wd->Nk = Nk; Wd->ncols = ncols; Wd->nrows = nrows;
     CP_HIP(hipStreamCreate(&Wd->stream));
     hipStream_t s = Wd->stream;
     DBuf<int32_t> keys((size_t)(Nk > 0 ? Nk : 1));
@@ -433,7 +433,7 @@ int32_t cp_domsum_build(cp_csr_t A, int32_t dtype, const void *val, cp_wsum_t *o
         CP_HIP(hipSetDevice(A->device));
         CP_HIP(hipStreamSynchronize(A->stream));
         return wsum_make(A->device, dtype, A->m, A->n, A->N, A->pos.p, A->row.p, nullptr, val, out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_rook_build(int64_t N, const int64_t *idx, int32_t dtype, const void *val, int32_t device, cp_wsum_t *out)
@@ -442,7 +442,7 @@ int32_t cp_rook_build(int64_t N, const int64_t *idx, int32_t dtype, const void *
         CP_REQUIRE(out && N >= 0 && (idx || N == 0) && N < ((int64_t)1 << 30), CP_EINVAL, "bad argument");
         CP_REQUIRE(cp_device_count() > 0, CP_EHIP, "no HIP device visible: libchainpart has no CPU fallback");
         return wsum_make(device, dtype, N, N, N, nullptr, nullptr, idx, val, out);
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_wsum_query(cp_wsum_t h, int64_t nq, const int64_t *i, const int64_t *j, int64_t *count_out, int64_t *sum_i64, double *sum_f64)
@@ -452,7 +452,7 @@ int32_t cp_wsum_query(cp_wsum_t h, int64_t nq, const int64_t *i, const int64_t *
         if (nq == 0) return CP_OK;
         CP_HIP(hipSetDevice(h->device));
         hipStream_t s = h->stream;
-        const int64_t nr = ((int64_t)1 << h->wt.d.H);
+        const int64_t nr = h->nrows;
         for (int64_t t = 0; t < nq; t++) CP_REQUIRE(i[t] >= 1 && i[t] <= nr + 1 && j[t] >= 1 && j[t] <= h->ncols + 1, CP_EINVAL, "S[i,j] needs 1<=i<=m+1, 1<=j<=n+1");
         DBuf<int64_t> da((size_t)nq), db((size_t)nq), dc((size_t)nq);
         DBuf<uint64_t> ds((size_t)nq);
@@ -471,7 +471,7 @@ int32_t cp_wsum_query(cp_wsum_t h, int64_t nq, const int64_t *i, const int64_t *
         CP_HIP(hipMemcpyAsync(h->dtype == CP_I64 ? (void *)sum_i64 : (void *)sum_f64, ds.p, 8 * (size_t)nq, hipMemcpyDeviceToHost, s));
         CP_HIP(hipStreamSynchronize(s));
         return CP_OK;
-    } catch (const HipFail &e) { return e.code; }
+    } CP_CATCH_ALL
 }
 
 int32_t cp_wsum_destroy(cp_wsum_t h)

@@ -123,14 +123,18 @@ def partition_stripe_tiled(hip, handle, n, K, method, *, device, group=None):
 
     Ordering: the handle's kernels are enqueued on torch's CURRENT stream (cp_set_stream), the stream the collective is
     ordered against, so layer k+1 cannot read `prev` before the gather of layer k has landed -- whatever stream context the
-    caller runs under.  The gather is in place: every rank's tile of `cur` is the send buffer (no clone, no device-wide sync)."""
+    caller runs under.  The gather is in place: every rank's tile of `cur` is the send buffer (no clone, no device-wide sync).
+    The binding lasts for this call only: on return the handle is back on a stream of its own (cp_reset_stream), so it never
+    outlives a torch stream it borrowed."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     host_staged = dist.get_backend(group) == "gloo"      # CPU rehearsal of the same exchange (tests); RCCL works on HBM
-    if torch.device(device).type == "cuda":
+    borrowed = torch.device(device).type == "cuda"
+    if borrowed:
         hip.set_stream(handle, torch.cuda.current_stream(device).cuda_stream)
-    T = TiledDP(hip, handle, n, K, method, rank, world, device)
+    T = None
     try:
+        T = TiledDP(hip, handle, n, K, method, rank, world, device)
         if not T.feasible:                              # DynamicSplitter.jl:217-222: a degenerate partition, no exception
             spl = np.ones(K + 1, dtype=np.int64)
             spl[K] = n + 1
@@ -150,6 +154,7 @@ def partition_stripe_tiled(hip, handle, n, K, method, *, device, group=None):
                 dist.all_gather(parts, mine.cpu(), group=group)
                 full = torch.cat(parts).to(device)
             elif T.windowed or off + t * world > T.cur.numel():
+                assert T.stage is not None, "a gathered range beyond the layer buffer needs the staging buffer"
                 full = T.stage[:t * world]
                 dist.all_gather_into_tensor(full, mine.contiguous(), group=group)
             else:
@@ -169,4 +174,7 @@ def partition_stripe_tiled(hip, handle, n, K, method, *, device, group=None):
             spl[k - 1] = int(v.item())
         return spl
     finally:
-        T.close()
+        if T is not None:
+            T.close()
+        if borrowed:
+            hip.reset_stream(handle)

@@ -207,6 +207,9 @@ int32_t cp_dp_destroy(cp_dp_t dp);
 /* ---- execution control / measurement ---- */
 /* run subsequent launches of this csr on an existing hipStream_t (e.g. torch's current stream) */
 int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
+/* back to a stream of the handle's own (waits for the borrowed one first): a handle must not stay bound to a caller's stream
+ * that may be destroyed before the handle is (chainpartitioners.jl_amd/distributed.py restores it when the tiled run returns) */
+int32_t cp_reset_stream(cp_csr_t csr);
 /* Library-wide tunables and test switches; results never depend on them (tests/test_gpu_dynamic.py runs every one against the
  * oracle).  "force_brute" 1: the general O(K n^2) device DP even where the O(K n log^2 n) scheme applies; "brute_max_n": its size
  * limit.  Layer driver of the O(K n log^2 n) scheme: "short_t"/"short_e" (tasks finished during setup),

@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 
 MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineWorkModel(0, 10, 1), cp.AffineWorkModel(3, 0, 1),
           cp.AffineHyperedgeCutModel(0, 1, 0, 3, 2), cp.AffineHyperedgeCutModel(0, 0, 0, 1, 1), cp.AffineConnectivityModel(0.5, 0.25, 0.0, 1.5),
-          cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[5, 1, 9, 2, 7, 3, 8, 4]), cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0)]
+          cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[5, 1, 9, 2, 7, 3, 8, 4]), cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0),
+          # non-integral hyperedge cut: OUTSIDE the valley class after rounding (tests/test_oracle_bottleneck.py) -> general sweep
+          cp.AffineHyperedgeCutModel(0., 0., 0., 0.7, 0.1), cp.AffineHyperedgeCutModel(0.3, 0.1, 0., 0.3, 0.3),
+          cp.AffineHyperedgeCutModel(0., 1., 0., 3., 2.)]
 
 
 def mats():

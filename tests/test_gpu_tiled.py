@@ -103,7 +103,9 @@ def test_tiled_constrained_tables_equal_the_oracle(hip, orc):
 
 
 def _tiled_worker(rank, world, port, q, backend="gloo"):
-    import os, sys
+    """Messages on `q`: ("skip", why) -- the process group could not be CREATED (the only excuse); ("up",) -- the group is up;
+    ("result", [...]) from rank 0; ("error", traceback) from any rank whose body raised after the group came up."""
+    import os, sys, traceback
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -119,24 +121,65 @@ def _tiled_worker(rank, world, port, q, backend="gloo"):
             return
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    import cpamd
-    cpm = cpamd.load()
-    from chainpartitioners_jl_amd import _lib
-    from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
-    from util import suitesparse_shaped as ss
-    hipb = _lib.HipBackend(0)
-    A = ss(4000, 6, 11)
-    K = 6
-    net = cpm.AffineConnectivityModel(0, 10, 1, 100)
-    out = []
-    for meth in (cpm.DynamicTotalSplitter(net), cpm.DynamicBottleneckSplitter(net),
-                 cpm.DynamicTotalSplitter(cpm.ConstrainedCost(net, cpm.VertexCount(), 1000))):
-        spl = partition_stripe_tiled(hipb, hipb.csr(A), A.n, K, meth, device=torch.device("cuda", 0))
-        out.append(spl.tolist())
     if rank == 0:
-        q.put(out)
-    dist.barrier()
-    dist.destroy_process_group()
+        q.put(("up",))
+    try:
+        import cpamd
+        cpm = cpamd.load()
+        from chainpartitioners_jl_amd import _lib
+        from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
+        from util import suitesparse_shaped as ss
+        hipb = _lib.HipBackend(0)
+        A = ss(4000, 6, 11)
+        K = 6
+        net = cpm.AffineConnectivityModel(0, 10, 1, 100)
+        out = []
+        for meth in (cpm.DynamicTotalSplitter(net), cpm.DynamicBottleneckSplitter(net),
+                     cpm.DynamicTotalSplitter(cpm.ConstrainedCost(net, cpm.VertexCount(), 1000))):
+            spl = partition_stripe_tiled(hipb, hipb.csr(A), A.n, K, meth, device=torch.device("cuda", 0))
+            out.append(spl.tolist())
+        if rank == 0:
+            q.put(("result", out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put(("error", "rank %d:\n%s" % (rank, traceback.format_exc())))
+        raise
+
+
+def _collect(q, procs, up_timeout, run_timeout):
+    """-> ("skip", why) | ("result", value); fails the test on an error message, a dead worker, or silence AFTER the group came up"""
+    import queue
+    up = False
+    deadline = up_timeout
+    while True:
+        try:
+            msg = q.get(timeout=deadline)
+        except queue.Empty:
+            for p in procs:
+                p.terminate()
+            for p in procs:
+                p.join(timeout=30)
+            if not up:
+                return ("skip", "the process group did not come up within %d s" % up_timeout)
+            pytest.fail("the process group came up but the tiled run gave no answer within %d s (exit codes %s)"
+                        % (run_timeout, [p.exitcode for p in procs]))
+        if msg[0] == "up":
+            up, deadline = True, run_timeout
+        elif msg[0] == "error":
+            for p in procs:
+                p.join(timeout=30)
+            pytest.fail("tiled worker raised after the group came up:\n" + msg[1])
+        else:
+            return msg
+
+
+def _want(orc):
+    A = suitesparse_shaped(4000, 6, 11)
+    net = cp.AffineConnectivityModel(0, 10, 1, 100)
+    return [cp.partition_stripe(A, 6, m, backend=orc).spl.tolist()
+            for m in (cp.DynamicTotalSplitter(net), cp.DynamicBottleneckSplitter(net),
+                      cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
 
 
 def test_tiled_two_processes_gloo(hip, orc):
@@ -150,15 +193,12 @@ def test_tiled_two_processes_gloo(hip, orc):
     procs = [ctx.Process(target=_tiled_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    kind, got = _collect(q, procs, 300, 300)
+    assert kind == "result", got                       # (gloo on localhost always comes up: no skip here)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    A = suitesparse_shaped(4000, 6, 11)
-    net = cp.AffineConnectivityModel(0, 10, 1, 100)
-    want = [cp.partition_stripe(A, 6, m, backend=orc).spl.tolist()
-            for m in (cp.DynamicTotalSplitter(net), cp.DynamicBottleneckSplitter(net),
-                      cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
+    want = _want(orc)
     assert got == want
     assert len(set(want[1])) > 2 and len(set(want[2])) > 2          # the last two are informative
 
@@ -167,7 +207,8 @@ def test_tiled_one_rank_over_rccl(hip, orc):
     """The tiled driver with the RCCL backend (backend "nccl"), one rank on this box's GPU: the per-layer all_gather_into_tensor of
     the cost tiles and the MAX all-reduces of unravel_splits go through RCCL on device tensors, ordered with the library's kernels
     by stream only (cp_set_stream on torch's current stream) -- the code path of bench.py --mode tiled, which a one-GPU box cannot
-    run with more ranks.  Results against the oracle."""
+    run with more ranks.  Results against the oracle.  The ONLY skip is a process group that cannot be created; a worker that
+    raises, dies or goes silent after the group is up fails the test (the old guard would have hidden a hang)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -175,18 +216,10 @@ def test_tiled_one_rank_over_rccl(hip, orc):
     q = ctx.Queue()
     p = ctx.Process(target=_tiled_worker, args=(0, 1, port, q, "nccl"))
     p.start()
-    try:
-        got = q.get(timeout=240)
-    except Exception:                                   # (a group that never comes up must not fail the suite)
-        p.terminate(); p.join(timeout=30)
-        pytest.skip("no answer from the RCCL worker within 240 s")
+    kind, got = _collect(q, [p], 240, 240)
+    if kind == "skip":
+        p.join(timeout=30)
+        pytest.skip("RCCL process group could not be created here: " + got)
     p.join(timeout=120)
-    if isinstance(got, tuple) and got and got[0] == "skip":
-        pytest.skip("RCCL process group could not be created here: " + got[1])
     assert p.exitcode == 0
-    A = suitesparse_shaped(4000, 6, 11)
-    net = cp.AffineConnectivityModel(0, 10, 1, 100)
-    want = [cp.partition_stripe(A, 6, m, backend=orc).spl.tolist()
-            for m in (cp.DynamicTotalSplitter(net), cp.DynamicBottleneckSplitter(net),
-                      cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.VertexCount(), 1000)))]
-    assert got == want
+    assert got == _want(orc)

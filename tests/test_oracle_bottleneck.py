@@ -44,3 +44,43 @@ def test_valley_search_reproduces_the_literal_bottleneck_tables(orc):
                 F = brute.cost_table(A, mdl, k)
                 c1, p1 = valley_layer(cst[:, k - 2], F)
                 assert np.array_equal(c1, cst[:, k - 1]) and np.array_equal(p1 + 1, ptr[:, k - 1]), (A, mdl.kind, k)
+
+
+def _literal_max_layer(W, F):
+    """DynamicSplitter.jl:33-46 with g = max as written: scan p upwards, `<=` keeps the largest minimiser"""
+    n1 = F.shape[0]
+    cst = np.zeros(n1, dtype=F.dtype); ptr = np.zeros(n1, dtype=np.int64)
+    for r in range(n1):
+        v = np.maximum(W[:r + 1], F[:r + 1, r])
+        i = v.size - 1 - int(np.argmin(v[::-1]))
+        cst[r], ptr[r] = v[i], i
+    return cst, ptr
+
+
+def test_non_integral_hyperedge_costs_are_outside_the_valley_class(orc):
+    """Why fast_bottleneck_ok (csrc/capi.hip) sends Float64 hyperedge-cut models with non-integral betas to the general sweep
+    (ADVICE round 2): the cost fl(l*b_self) + fl((d-l)*b_cut) is not monotone in the part after rounding, so the valley search
+    is NOT the literal DP for them -- while a literal sweep over the same rounded cost table is.  Work / Connectivity models with
+    non-integral parameters stay inside the class (every term is monotone)."""
+    rng = np.random.default_rng(5)
+    mats = [sprand(8, 16, 0.3, rng), sprand(10, 23, 0.2, rng), sprand(6, 33, 0.3, rng), sprand(20, 40, 0.1, rng), suitesparse_shaped(60, 3, 5),
+            sprand(3, 12, 0.6, rng)]
+    K = 5
+    bad_valley = 0
+    for A in mats:
+        for mdl in (cp.AffineHyperedgeCutModel(0., 0., 0., 0.1, 0.1), cp.AffineHyperedgeCutModel(0., 0., 0., 0.7, 0.1),
+                    cp.AffineHyperedgeCutModel(0.3, 0.1, 0., 0.3, 0.3)):
+            rc, ptr, cst = orc.dynamic_tables(A, K, 1, mdl.marshal(), None)
+            assert rc == 0
+            for k in range(2, K):
+                F = brute.cost_table(A, mdl, k)
+                c0, p0 = _literal_max_layer(cst[:, k - 2], F)
+                assert np.array_equal(c0, cst[:, k - 1]) and np.array_equal(p0 + 1, ptr[:, k - 1]), (A, k)      # the literal sweep IS the oracle
+                c1, p1 = valley_layer(cst[:, k - 2], F)
+                bad_valley += int(not (np.array_equal(c1, cst[:, k - 1]) and np.array_equal(p1 + 1, ptr[:, k - 1])))
+        for mdl in (cp.AffineConnectivityModel(0.1, 0.7, 0.3, 0.1), cp.AffineWorkModel(0.3, 0.1, 0.7)):
+            rc, ptr, cst = orc.dynamic_tables(A, K, 1, mdl.marshal(), None)
+            for k in range(2, K):
+                c1, p1 = valley_layer(cst[:, k - 2], brute.cost_table(A, mdl, k))
+                assert np.array_equal(c1, cst[:, k - 1]) and np.array_equal(p1 + 1, ptr[:, k - 1]), (A, mdl.kind, k)
+    assert bad_valley > 0          # (the advisor counted 35 of 360 layers on a similar set)
