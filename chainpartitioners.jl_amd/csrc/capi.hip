@@ -625,6 +625,8 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
+    if (!strcmp(name, "leaf")) { g_opt_leaf = value; return CP_OK; }
+    if (!strcmp(name, "block_tables")) { g_opt_block_tables = value; return CP_OK; }
     if (!strcmp(name, "rpass_small_tau")) { g_opt_rpass_small_tau = value; return CP_OK; }
     if (!strcmp(name, "force_max")) { g_opt_force_max = value < 0 ? 0 : value; return CP_OK; }
     if (!strcmp(name, "setup_bs")) { int64_t v = 64; while (v < value && v < 1024) v <<= 1; g_opt_setup_bs = v; return CP_OK; }

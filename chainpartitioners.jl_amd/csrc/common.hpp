@@ -68,7 +68,7 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ------------------------------------------------------------------ per-kernel HIP-event profiling
 struct ProfSlot { const char *name; int64_t launches; double ms; double alg_bytes; };
 enum { PROF_EXPAND = 0, PROF_EVAL, PROF_SETUP, PROF_SCAN, PROF_CARRY, PROF_FIX, PROF_COMBINE, PROF_LINKS,
-       PROF_BRUTE, PROF_WAVELET, PROF_QUERY, PROF_BISECT, PROF_CHUNK, PROF_RPASS, PROF_OWN, PROF_GAP, PROF_GAPSTREAM, PROF_RA, PROF_NSLOTS };
+       PROF_BRUTE, PROF_WAVELET, PROF_QUERY, PROF_BISECT, PROF_CHUNK, PROF_RPASS, PROF_OWN, PROF_GAP, PROF_GAPSTREAM, PROF_RA, PROF_LEAF, PROF_NSLOTS };
 extern ProfSlot g_prof[PROF_NSLOTS];
 extern bool g_prof_on;
 extern int g_prof_only;              // >= 0: only this slot records events (cp_set_option("prof_only")): 2 events per round instead of ~40

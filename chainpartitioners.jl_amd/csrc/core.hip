@@ -14,7 +14,7 @@ ProfSlot g_prof[PROF_NSLOTS] = {
     {"dp_lpass", 0, 0, 0}, {"dp_open_segments", 0, 0, 0}, {"dp_task_setup", 0, 0, 0},
     {"scan", 0, 0, 0}, {"dp_tile_carry", 0, 0, 0}, {"dp_span_fix", 0, 0, 0}, {"dp_combine", 0, 0, 0},
     {"link_build", 0, 0, 0}, {"dp_brute", 0, 0, 0}, {"wavelet_build", 0, 0, 0}, {"count_query", 0, 0, 0},
-    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}, {"dp_lpass_gap", 0, 0, 0}, {"dp_round_a", 0, 0, 0}};
+    {"bisect_probe", 0, 0, 0}, {"chunker", 0, 0, 0}, {"dp_rpass", 0, 0, 0}, {"dp_lpass_own", 0, 0, 0}, {"dp_gap_finish", 0, 0, 0}, {"dp_lpass_gap", 0, 0, 0}, {"dp_round_a", 0, 0, 0}, {"dp_leaf", 0, 0, 0}};
 bool g_prof_on = false;
 int g_prof_only = -1;
 std::vector<ProfPending> g_prof_pending;

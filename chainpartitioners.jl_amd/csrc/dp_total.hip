@@ -1828,10 +1828,12 @@ __global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                  const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                                 TC *__restrict__ cst, int32_t *__restrict__ ptr)
+                                                 TC *__restrict__ cst, int32_t *__restrict__ ptr, int sh)
 {
-    const int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
+    // sh > 0 (after a leaf pass): the rows (rlo + i) << sh only -- the leaf rows were combined where they were computed
+    int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
     if (r < 0) return;
+    r <<= sh;
     int64_t n1 = n + 1;
     TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
     int64_t bp = r;
@@ -2229,6 +2231,8 @@ __global__ void k_round_finish(RoundCounts *__restrict__ rc, int64_t capT, int64
     rc->ntile = (int32_t)((rc->T + LT - 1) / LT);
 }
 
+#include "dp_leaf.inc"
+
 // ------------------------------------------------------------------ host driver for one layer
 template <typename TC>
 struct LayerWork {
@@ -2264,6 +2268,7 @@ struct LayerWork {
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
+    bool planes_full = false;                           // the last layer stored every per-block winner (cp_dp_block_tables)
     // windowed layers: geometry of the current call; anchors of the mirrored head tasks, cached per (pattern, w)
     Geo G{0, 0, 0};
     bool win_built = false; int64_t win_w = -1, win_nitems = 0, win_aoff[33];
@@ -2566,6 +2571,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     const int NR = nbits + 1;
     CP_HIP(hipMemsetAsync(Wk.rc.p, 0, sizeof(RoundCounts) * (size_t)NR, s));
     const bool gaps = own_tiles && g_opt_gap_tau >= 0;
+    const bool leaf = g_opt_leaf && !G.win;                 // the rounds tau < LEAF_T are one pass over groups of 64 rows (dp_leaf.inc)
+    Wk.planes_full = !leaf || g_opt_block_tables;
     CP_HIP(hipMemsetAsync(Wk.fin.p, 0, Wk.fin.bytes(), s));
     std::vector<RoundCounts> used((size_t)NR);          // what the host sized each round with
     memset(used.data(), 0, sizeof(RoundCounts) * (size_t)NR);
@@ -2579,6 +2586,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi, G, Wk.win_aoff);
         else make_round(R, false, nbits - rd, nbits, n, rlo, rhi, G, Wk.win_aoff);
+        if (leaf && !R.isA && R.tau < LEAF_T) continue;
         if (rd == 0 && g_opt_ra_cache && rlo <= 1 && rhi >= n && n >= 1 && !G.win) {
             // a full layer: round A of the rows' lowest blocks from the cached counts; what is left of round A below is the
             // last row in its upper planes
@@ -2916,7 +2924,38 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         }
         CP_HIP(hipGetLastError());
     }
-    {
+    if (leaf) {
+        // every row that is not a multiple of 64: inner planes, outer planes and the combine in one pass (dp_leaf.inc)
+        const int64_t c0 = rlo > 1 ? rlo : 1, c1 = rhi < n ? rhi : n;
+        if (c1 >= c0) {
+            const int64_t g0 = c0 >> LEAF_T, g1 = c1 >> LEAF_T;
+            // bytes: the group's link entries twice (prev, next), column pointers, previous-layer costs, the two output rows
+            ProfScope ps(PROF_LEAF, s, (8.0 * (avg_deg + self_deg) + 4.0 + 8.0 + 12.0) * (double)((g1 - g0 + 1) << LEAF_T));
+            LeafArgs<TC, false> L0{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, Wk.opt.p, Wk.nnopt.p, nullptr, Wk.fin.p, W, M, alpha, cst_out, ptr_out};
+            if (hyp) {
+                LeafArgs<TC, true> L1{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
+                                      A->fpos32.p, A->flast.p, A->ffirst.p, A->lpos32.p, A->lfirst.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, W, M, alpha,
+                                      cst_out, ptr_out};
+                const unsigned lg = (unsigned)cdiv(L1.ngroups, LeafWPB<true>::v);
+                if (nbits <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 18>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
+                else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 25>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
+            } else {
+                const unsigned lg = (unsigned)cdiv(L0.ngroups, LeafWPB<false>::v);
+                if (nbits <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, false, 18>), dim3(lg), dim3(64 * LeafWPB<false>::v), 0, s, L0);
+                else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, false, 25>), dim3(lg), dim3(64 * LeafWPB<false>::v), 0, s, L0);
+            }
+            CP_HIP(hipGetLastError());
+        }
+    }
+    if (leaf) {
+        ProfScope ps(PROF_COMBINE, s, 24.0 * (double)((n >> LEAF_T) + 1));
+        const int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
+        const int64_t f0 = (c0 + LEAF_G - 1) >> LEAF_T, f1 = c1 >> LEAF_T;       // the multiples of 64 in [c0, c1]
+        if (c1 >= c0 && f1 >= f0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(f1 - f0 + 1, 256)), dim3(256), 0, s, 0, n, f0, f1, nbits, A->pos32.p,
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, LEAF_T);
+    } else {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
         int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
         // threads in row order.  (lvl = 1, cp_set_option("dbg", 16384): in plane-slot order, so that the dozen plane reads of a row are
@@ -2929,7 +2968,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                            Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
         else if (c1 >= c0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, n, c0, c1, nbits, A->pos32.p,
-                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, 0);
     }
     CP_HIP(hipGetLastError());
     // ---- the true counts of every round: the next layer's prediction, this layer's verdict
@@ -3046,6 +3085,7 @@ int dp_total_block_tables(cp_csr_s *A, void *work_, int64_t *opt_out, int64_t *n
     auto &Wk = *reinterpret_cast<LayerWork<TC> *>(work_);
     const int64_t n = A->n, n1 = n + 1;
     CP_REQUIRE(Wk.n == n && Wk.opt.p, CP_EINVAL, "no layer has been computed by the O(n log^2 n) scheme on this handle");
+    CP_REQUIRE(Wk.planes_full, CP_EINVAL, "the last layer kept no per-block winners for its leaf rows: cp_set_option(\"block_tables\", 1) before the layer");
     const size_t plane = (size_t)Wk.nbits * (size_t)n1;
     std::vector<int32_t> ho(plane), hn(plane), hl;
     CP_HIP(hipMemcpyAsync(ho.data(), Wk.opt.p, plane * sizeof(int32_t), hipMemcpyDeviceToHost, A->stream));

@@ -23,9 +23,11 @@ MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(1, 
           cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0), cp.AffineHyperedgeCutModel(0.0, 1.0, 0.0, -1.0, 2.0)]
 
 OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"ra_cache": 0}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
-           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"force_max": 1000000}, {"dbg": 262144}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048}]
+           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"force_max": 1000000}, {"dbg": 262144}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048},
+           # the rounds tau < 6 as divide-and-conquer rounds (the path before the leaf pass, csrc/dp_leaf.inc), alone and with the gap passes reaching down
+           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}, {"leaf": 0, "short_t": 0, "short_e": 0}]
 DEFAULTS = {"nospec": 0, "gap_tau": 6, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024,
-            "short_t": 8, "short_e": 64, "own_min": 64}
+            "short_t": 8, "short_e": 64, "own_min": 64, "leaf": 1}
 
 
 def w_rows(rng, n, scale, dt):
@@ -57,6 +59,8 @@ def check_layer(hip, A, T, mdl, W_rows, tile=None, check_blocks=True):
     lo, hi = tile if tile else (1, n + 2)
     dp = hip.dp_begin(A, 3, 0, 0, mm, lo, hi)
     moved = 0
+    # the leaf pass combines its rows where it computes them; the per-block winners are stored only on request
+    assert hip.set_option("block_tables", 1 if (check_blocks and tile is None) else 0) == 0
     try:
         F = T.F(mdl, 2)
         nb = max(1, int(n).bit_length())
@@ -82,6 +86,7 @@ def check_layer(hip, A, T, mdl, W_rows, tile=None, check_blocks=True):
                 if hyper:
                     assert np.array_equal(nl[bs, rs], T.ST[ob[bs, rs], rs])
     finally:
+        hip.set_option("block_tables", 0)
         hip.dp_destroy(dp)
     return moved
 
@@ -121,6 +126,8 @@ def test_block_argmins_every_layer_option(hip, oi):
                 dt = np.int64 if mdl.dtype == cp.models.CP_I64 else np.float64
                 scale = int(abs(T.F(mdl, 2)).max()) + 1
                 moved += check_layer(hip, A, T, mdl, w_rows(rng, A.n, scale, dt))
+                # ... and as production runs it: no plane stores from the leaf rows, cst / ptr only
+                check_layer(hip, A, T, mdl, w_rows(rng, A.n, scale, dt)[:2], check_blocks=False)
         assert moved > 10000
     finally:
         for k, v in DEFAULTS.items():
