@@ -21,7 +21,7 @@ SYMBOLS = [
     "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise", "cp_domsum_build", "cp_rook_build", "cp_wsum_query", "cp_wsum_destroy",
     "cp_oracle_eval", "cp_oracle_step", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
-    "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_reset_stream", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
+    "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_reset_stream", "cp_get_stat", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window", "cp_dp_set_rows",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
     "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
@@ -133,6 +133,13 @@ class HipBackend:
     def reset_stream(self, A_or_handle):
         h = A_or_handle if isinstance(A_or_handle, C.c_void_p) else self.csr(A_or_handle)
         return self.lib.cp_reset_stream(h)
+
+    def get_stat(self, name):
+        out = C.c_int64()
+        rc = self.lib.cp_get_stat(name.encode(), C.byref(out))
+        if rc != 0:
+            raise KeyError(name)
+        return out.value
 
     def set_option(self, name, value):
         return self.lib.cp_set_option(name.encode(), _i64(value))

@@ -598,6 +598,14 @@ int32_t cp_set_stream(cp_csr_t A, void *hip_stream)
     return CP_OK;
 }
 
+int32_t cp_get_stat(const char *name, int64_t *out)
+{
+    if (!name || !out) return CP_EINVAL;
+    if (!strcmp(name, "spec_redo")) { *out = g_spec_redo; return CP_OK; }
+    if (!strcmp(name, "poison_hits")) { *out = g_poison_hits; return CP_OK; }
+    return CP_EINVAL;
+}
+
 int32_t cp_reset_stream(cp_csr_t A)
 {
     if (!A) return CP_EINVAL;
@@ -626,6 +634,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "leaf")) { g_opt_leaf = value; return CP_OK; }
+    if (!strcmp(name, "poison")) { g_opt_poison = value; if (value) { g_poison_hits = 0; g_spec_redo = 0; } return CP_OK; }
     if (!strcmp(name, "block_tables")) { g_opt_block_tables = value; return CP_OK; }
     if (!strcmp(name, "rpass_small_tau")) { g_opt_rpass_small_tau = value; return CP_OK; }
     if (!strcmp(name, "force_max")) { g_opt_force_max = value < 0 ? 0 : value; return CP_OK; }

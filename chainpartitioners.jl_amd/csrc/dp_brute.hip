@@ -28,6 +28,7 @@ int64_t g_opt_nospec = 0, g_spec_redo = 0;
 int64_t g_opt_gap_tau = 6, g_opt_gap_min = 64;
 int64_t g_opt_ra_cache = 1;
 int64_t g_opt_leaf = 1, g_opt_block_tables = 0;
+int64_t g_opt_poison = 0, g_poison_hits = 0;
 int64_t g_opt_fixed_point = 0;
 int64_t g_opt_brute_max_n = 200000;
 int64_t g_opt_dbg = 0;

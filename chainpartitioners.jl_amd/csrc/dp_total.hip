@@ -486,8 +486,11 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
                                                       int32_t *__restrict__ o_ntl, int32_t *__restrict__ o_tS0l, int32_t *__restrict__ n_own,
                                                       unsigned long long *__restrict__ own_steps, int32_t OWN_MIN, int32_t o_cap,
                                                       int32_t *__restrict__ err, const uint8_t *__restrict__ fin, const int32_t *__restrict__ last_s0,
-                                                      int32_t *__restrict__ dbg_ntriv, const int32_t *__restrict__ anch, const int32_t *__restrict__ anch2)
+                                                      int32_t *__restrict__ dbg_ntriv, const int32_t *__restrict__ anch, const int32_t *__restrict__ anch2,
+                                                      int32_t *__restrict__ pz)
 {
+    // pz (cp_set_option("poison", 1)): the planes were filled with an out-of-range column before the layer; a task whose bounds
+    // come out of range has read a cell nobody wrote -- counted, and clamped so that the task stays well-formed
     int lane = threadIdx.x & 63;
     bool live;
     bool is_long = false, is_own = false, is_short = false;
@@ -556,6 +559,10 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
         }
     }
     if (finb) live = false;
+    if (live && pz && !R.isA && ((uint64_t)B > (uint64_t)R.n || (uint64_t)a > (uint64_t)R.n)) {
+        atomicAdd(pz, 1);
+        B = B < 0 ? 0 : (B > R.n ? R.n : B); a = a < 0 ? 0 : (a > B ? B : a);
+    }
     if (live) {
         int64_t L = 1 + (B - a);
         if (dbg_ntriv && L > 1 && !R.isA) atomicAdd(dbg_ntriv, 1);
@@ -1828,7 +1835,7 @@ __global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo
                                                  const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                  const int32_t *__restrict__ nlopt,
                                                  const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                                 TC *__restrict__ cst, int32_t *__restrict__ ptr, int sh)
+                                                 TC *__restrict__ cst, int32_t *__restrict__ ptr, int sh, int32_t *__restrict__ pz)
 {
     // sh > 0 (after a leaf pass): the rows (rlo + i) << sh only -- the leaf rows were combined where they were computed
     int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
@@ -1840,6 +1847,7 @@ __global__ void __launch_bounds__(256) k_combine(int lvl, int64_t n, int64_t rlo
     for (int b = 0; b < nbits; b++) {
         if (!((r >> b) & 1)) continue;
         int64_t p = opt[(int64_t)b * n1 + PR(r)];
+        if (pz && (uint64_t)p > (uint64_t)n) { atomicAdd(pz, 1); p = r; }      // (poison mode: a cell nobody wrote)
         int64_t nn = nnopt[(int64_t)b * n1 + PR(r)];
         int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + PR(r)] : 0;
         TC v = cadd(W[p], dm_apply(M, alpha, r - p, (int64_t)(pos[r] - pos[p]), nn, nl));
@@ -1856,10 +1864,11 @@ __global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, 
                                                      const int32_t *__restrict__ opt, const int32_t *__restrict__ nnopt,
                                                      const int32_t *__restrict__ nlopt,
                                                      const TC *__restrict__ W, DevModel<TC> M, TC alpha,
-                                                     TC *__restrict__ cst, int32_t *__restrict__ ptr)
+                                                     TC *__restrict__ cst, int32_t *__restrict__ ptr, int sh, int32_t *__restrict__ pz)
 {
-    const int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
+    int64_t r = combine_row((int64_t)blockIdx.x * blockDim.x + threadIdx.x, n, rlo, rhi, lvl);
     if (r < 0) return;
+    r <<= sh;                                                   // (after a leaf pass: the multiples of 64 only)
     const int64_t n1 = n + 1;
     TC bv = cadd(W[r], dm_apply(M, alpha, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0));   // j = j' (empty part)
     int64_t bp = r;
@@ -1871,7 +1880,8 @@ __global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, 
             if (b == G.s && i != G.s) continue;
             int64_t cs, ce;
             if (!geo_block(G, r, b, cs, ce)) continue;
-            const int64_t p = opt[(int64_t)b * n1 + slot];
+            int64_t p = opt[(int64_t)b * n1 + slot];
+            if (pz && (uint64_t)p > (uint64_t)n) { atomicAdd(pz, 1); p = r; }
             const int64_t nn = nnopt[(int64_t)b * n1 + slot];
             const int64_t nl = nlopt ? nlopt[(int64_t)b * n1 + slot] : 0;
             const TC v = cadd(W[p], dm_apply(M, alpha, r - p, (int64_t)(pos[r] - pos[p]), nn, nl));
@@ -1942,6 +1952,16 @@ __global__ void __launch_bounds__(256) k_win_anchors(RoundDesc R, int64_t nitems
     int64_t v = base[rho] - E[rho];
     for (int bb = 0; bb <= b; bb++) v -= tot[R.aoff[bb] + (rho >> (bb + 1))];
     anch[it] = (int32_t)v;
+}
+
+// leaf pass: the part [64 g + 62 - w, 64 g) of every group (E from the histogram of width w - 62)
+__global__ void __launch_bounds__(256) k_leaf_anchors(int64_t ng, int64_t n, const int64_t *__restrict__ base, const int64_t *__restrict__ E,
+                                                      int32_t *__restrict__ anch)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const int64_t r = g << 6;
+    anch[g] = r <= n ? (int32_t)(base[r] - E[r]) : 0;
 }
 
 // ------------------------------------------------------------------ round A from cached counts
@@ -2269,10 +2289,12 @@ struct LayerWork {
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
     bool planes_full = false;                           // the last layer stored every per-block winner (cp_dp_block_tables)
+    DBuf<int32_t> pz;                                   // poison mode: cells read that nobody wrote
     // windowed layers: geometry of the current call; anchors of the mirrored head tasks, cached per (pattern, w)
     Geo G{0, 0, 0};
     bool win_built = false; int64_t win_w = -1, win_nitems = 0, win_aoff[33];
     DBuf<int32_t> w_anch, w_anch2, w_tot, w_hist;
+    DBuf<int32_t> leaf_anch, leaf_anch2;                // leaf pass of windowed layers: nets / self nets of [64 g + 62 - w, 64 g) per group
     DBuf<int64_t> w_E;
     DBuf<RoundCounts> rc;                               // per-round counters of the current layer (device)
     std::vector<RoundCounts> pred;                      // ... of the previous layer (host): sizes the next one
@@ -2500,6 +2522,23 @@ static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
         }
         CP_HIP(hipGetLastError());
     }
+    // leaf pass (dp_leaf.inc): anchors of the inner mirrored blocks, nets(64 g + 62 - w, 64 g) for every group g -- the same
+    // histogram with the width w - 62
+    Wk.leaf_anch.release(); Wk.leaf_anch2.release();
+    if (sb >= LEAF_T && w > 62) {
+        const int64_t ng = (n >> LEAF_T) + 1;
+        Wk.leaf_anch.alloc((size_t)ng);
+        if (Wk.hyp) Wk.leaf_anch2.alloc((size_t)ng);
+        for (int pass = 0; pass < (Wk.hyp ? 2 : 1); pass++) {
+            CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
+            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, A->N, n, w - 62, A->col.p, A->next.p, Wk.w_hist.p); }
+            else if (A->m > 0) hipLaunchKernelGGL(k_win_hist_rows, dim3((unsigned)cdiv(A->m, 256)), dim3(256), 0, s, A->m, n, w - 62, A->rfirst.p, A->rlast.p, Wk.w_hist.p);
+            exclusive_scan_i32(Wk.w_hist.p, Wk.w_E.p, n + 1, Wk.scratch, s);
+            hipLaunchKernelGGL(k_leaf_anchors, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, s, ng, n, pass == 0 ? A->pos.p : A->lpos.p, Wk.w_E.p,
+                               pass == 0 ? Wk.leaf_anch.p : Wk.leaf_anch2.p);
+        }
+        CP_HIP(hipGetLastError());
+    }
     Wk.win_built = true; Wk.win_w = w;
 }
 
@@ -2571,7 +2610,21 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     const int NR = nbits + 1;
     CP_HIP(hipMemsetAsync(Wk.rc.p, 0, sizeof(RoundCounts) * (size_t)NR, s));
     const bool gaps = own_tiles && g_opt_gap_tau >= 0;
-    const bool leaf = g_opt_leaf && !G.win;                 // the rounds tau < LEAF_T are one pass over groups of 64 rows (dp_leaf.inc)
+    // cp_set_option("poison", 1) (tests): every layer starts from planes full of an out-of-range column; the kernels that turn
+    // plane cells into addresses count and clamp what they read of it.  The invariant behind the speculative layers -- "whatever a
+    // layer that is NOT redone has read was written by that layer" -- then reads: hits > 0 implies the layer is flagged for a redo.
+    int32_t *pzp = nullptr;
+    if (g_opt_poison) {
+        Wk.pz.ensure(2);
+        pzp = Wk.pz.p;
+        CP_HIP(hipMemsetAsync(Wk.pz.p, 0, sizeof(int32_t) * 2, s));
+        CP_HIP(hipMemsetAsync(Wk.opt.p, 0x7F, Wk.opt.bytes(), s));
+        CP_HIP(hipMemsetAsync(Wk.nnopt.p, 0x7F, Wk.nnopt.bytes(), s));
+        if (hyp) CP_HIP(hipMemsetAsync(Wk.nlopt.p, 0x7F, Wk.nlopt.bytes(), s));
+    }
+    // the rounds tau < LEAF_T are one pass over groups of 64 rows (dp_leaf.inc); windowed layers: when the window spans a group
+    // (s >= 6) and no per-block table is asked for
+    const bool leaf = g_opt_leaf && (!G.win || (G.s >= LEAF_T && !g_opt_block_tables && Wk.leaf_anch.p));
     Wk.planes_full = !leaf || g_opt_block_tables;
     CP_HIP(hipMemsetAsync(Wk.fin.p, 0, Wk.fin.bytes(), s));
     std::vector<RoundCounts> used((size_t)NR);          // what the host sized each round with
@@ -2718,7 +2771,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 hyp ? A->flast.p : (const int32_t *)nullptr, W, M, alpha, Wk.tdesc.p, Wk.tb.p, Wk.len.p, Wk.tS0l.p, &rc->nlong,               \
                 (int32_t)g_opt_short_t, (int32_t)g_opt_short_e, own_tiles ? Wk.o_tdesc.p : (int4 *)nullptr, Wk.o_tb.p, Wk.o_rlen.p, Wk.o_ntl.p,            \
                 Wk.o_tS0l.p, &rc->nown, &rc->own_steps, (int32_t)(forced ? 2 : gap ? g_opt_gap_min : g_opt_own_min),                                         \
-                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr, Wk.w_anch.p, Wk.w_anch2.p
+                (int32_t)std::min<size_t>(Wk.o_ntl.n, (size_t)INT32_MAX), &rc->err, Wk.fin.p, Wk.last_s0.p, (g_opt_dbg & 4096) ? &rc->_pad : (int32_t *)nullptr, Wk.w_anch.p, Wk.w_anch2.p, pzp
             const int sbs = (int)g_opt_setup_bs;          // lanes per block: one list atomic per block, but the block's waves meet at two barriers
             dim3 sgrid((unsigned)cdiv(R.ntask, sbs));
             if (!R.isA) {                                // one grid row per bit plane above tau
@@ -2931,18 +2984,27 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             const int64_t g0 = c0 >> LEAF_T, g1 = c1 >> LEAF_T;
             // bytes: the group's link entries twice (prev, next), column pointers, previous-layer costs, the two output rows
             ProfScope ps(PROF_LEAF, s, (8.0 * (avg_deg + self_deg) + 4.0 + 8.0 + 12.0) * (double)((g1 - g0 + 1) << LEAF_T));
+            const int need = G.win ? G.s - LEAF_T + 2 : nbits - LEAF_T;           // outer planes a group can have (+ the pseudo-plane)
+            CP_REQUIRE(need <= 25, CP_EINTERNAL, "leaf pass: more outer planes than counters");
+            // With a gap pass in round 6 every task of that round with gap_min candidates or more has finished its rows (and the
+            // ranges of a leaf group in a plane b > 6 lie inside the range of the round-6 task of one of its two bounding rows): a longer
+            // range in a leaf group can only come from plane cells a mispredicted speculative layer never wrote (zeros after
+            // allocation: a range of millions of candidates per group, seconds of work for a layer that is redone anyway).  Such a
+            // group flags the layer (err) and skips the plane.
+            const int32_t lcap = (gaps && g_opt_gap_tau >= LEAF_T) ? (int32_t)std::max<int64_t>(g_opt_gap_min, 2) : INT32_MAX;
             LeafArgs<TC, false> L0{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
-                                   nullptr, nullptr, nullptr, nullptr, nullptr, Wk.opt.p, Wk.nnopt.p, nullptr, Wk.fin.p, W, M, alpha, cst_out, ptr_out};
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, Wk.opt.p, Wk.nnopt.p, nullptr, Wk.fin.p, W, M, alpha, cst_out, ptr_out,
+                                   G, Wk.leaf_anch.p, nullptr, lcap, &Wk.rc.p->err, pzp};
             if (hyp) {
                 LeafArgs<TC, true> L1{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
                                       A->fpos32.p, A->flast.p, A->ffirst.p, A->lpos32.p, A->lfirst.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, W, M, alpha,
-                                      cst_out, ptr_out};
+                                      cst_out, ptr_out, G, Wk.leaf_anch.p, Wk.leaf_anch2.p, lcap, &Wk.rc.p->err, pzp};
                 const unsigned lg = (unsigned)cdiv(L1.ngroups, LeafWPB<true>::v);
-                if (nbits <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 18>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
+                if (need <= 18) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 18>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
                 else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 25>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
             } else {
                 const unsigned lg = (unsigned)cdiv(L0.ngroups, LeafWPB<false>::v);
-                if (nbits <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, false, 18>), dim3(lg), dim3(64 * LeafWPB<false>::v), 0, s, L0);
+                if (need <= 18) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, false, 18>), dim3(lg), dim3(64 * LeafWPB<false>::v), 0, s, L0);
                 else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, false, 25>), dim3(lg), dim3(64 * LeafWPB<false>::v), 0, s, L0);
             }
             CP_HIP(hipGetLastError());
@@ -2952,9 +3014,12 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)((n >> LEAF_T) + 1));
         const int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
         const int64_t f0 = (c0 + LEAF_G - 1) >> LEAF_T, f1 = c1 >> LEAF_T;       // the multiples of 64 in [c0, c1]
-        if (c1 >= c0 && f1 >= f0)
+        if (c1 >= c0 && f1 >= f0 && G.win)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(f1 - f0 + 1, 256)), dim3(256), 0, s, 0, G, n, f0, f1, A->pos32.p,
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, LEAF_T, pzp);
+        else if (c1 >= c0 && f1 >= f0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(f1 - f0 + 1, 256)), dim3(256), 0, s, 0, n, f0, f1, nbits, A->pos32.p,
-                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, LEAF_T);
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, LEAF_T, pzp);
     } else {
         ProfScope ps(PROF_COMBINE, s, 24.0 * (double)(n + 1));
         int64_t c0 = rlo > 0 ? rlo : 0, c1 = rhi < n ? rhi : n;
@@ -2965,15 +3030,17 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         const int64_t nthr = lvl ? n + 1 : c1 - c0 + 1;
         if (c1 >= c0 && G.win)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine_win<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, G, n, c0, c1, A->pos32.p,
-                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out);
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, 0, pzp);
         else if (c1 >= c0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_combine<TC>), dim3((unsigned)cdiv(nthr, 256)), dim3(256), 0, s, lvl, n, c0, c1, nbits, A->pos32.p,
-                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, 0);
+                           Wk.opt.p, Wk.nnopt.p, hyp ? Wk.nlopt.p : (const int32_t *)nullptr, W, M, alpha, cst_out, ptr_out, 0, pzp);
     }
     CP_HIP(hipGetLastError());
     // ---- the true counts of every round: the next layer's prediction, this layer's verdict
     std::vector<RoundCounts> got((size_t)NR);
+    int32_t pz_hits[2] = {0, 0};
     CP_HIP(hipMemcpyAsync(got.data(), Wk.rc.p, sizeof(RoundCounts) * (size_t)NR, hipMemcpyDeviceToHost, s));
+    if (pzp) CP_HIP(hipMemcpyAsync(pz_hits, pzp, sizeof(pz_hits), hipMemcpyDeviceToHost, s));
     CP_HIP(hipStreamSynchronize(s));
     bool ok = true;
     for (int rd = 0; rd < NR; rd++) {
@@ -2982,6 +3049,10 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         if (g.err) ok = false;                                                                  // a buffer was too small (the caller runs the layer again, plainly)
         if (g.nown > 0 && g.NT > 0 && !(u.nown > 0 && u.NT > 0)) ok = false;                    // a stage was skipped
         if (g.nlong > 0 && g.T > 0 && !(u.nlong > 0 && u.T > 0)) ok = false;
+    }
+    if (pzp) {
+        g_poison_hits += pz_hits[0];
+        CP_REQUIRE(!(ok && pz_hits[0] > 0), CP_EINTERNAL, "a DP layer that is not redone read plane cells nobody wrote (poison mode)");
     }
     if (ok) {
         for (auto &pt : patches) {

@@ -210,6 +210,11 @@ int32_t cp_set_stream(cp_csr_t csr, void *hip_stream);
 /* back to a stream of the handle's own (waits for the borrowed one first): a handle must not stay bound to a caller's stream
  * that may be destroyed before the handle is (chainpartitioners.jl_amd/distributed.py restores it when the tiled run returns) */
 int32_t cp_reset_stream(cp_csr_t csr);
+/* diagnostics counters of the library (tests): "spec_redo" -- DP layers enqueued from the previous layer's counts that had to be
+ * run again with exact counts; "poison_hits" -- with cp_set_option("poison", 1): plane cells read that the layer had not written
+ * (each such layer must be one of the redone ones; the library checks it and fails with CP_EINTERNAL otherwise).  Both are reset
+ * when "poison" is switched on. */
+int32_t cp_get_stat(const char *name, int64_t *out);
 /* Library-wide tunables and test switches; results never depend on them (tests/test_gpu_dynamic.py runs every one against the
  * oracle).  "force_brute" 1: the general O(K n^2) device DP even where the O(K n log^2 n) scheme applies; "brute_max_n": its size
  * limit.  Layer driver of the O(K n log^2 n) scheme: "short_t"/"short_e" (tasks finished during setup),

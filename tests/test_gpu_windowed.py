@@ -60,8 +60,10 @@ def test_constrained_tables_bit_exact(hip, orc, mi):
 
 
 OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
-           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 1048576}, {"dbg": 2097152}, {"dbg": 8388608}, {"ra_cache": 0}, {"force_max": 1000000}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048}]
-DEFAULTS = {"ra_cache": 1, "nospec": 0, "gap_tau": 6, "gap_min": 64, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "short_t": 8, "short_e": 64, "own_min": 64}
+           {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 1048576}, {"dbg": 2097152}, {"dbg": 8388608}, {"ra_cache": 0}, {"force_max": 1000000}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048},
+           # without the leaf pass (csrc/dp_leaf.inc): the rounds tau < 6 as divide-and-conquer rounds
+           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}]
+DEFAULTS = {"leaf": 1, "ra_cache": 1, "nospec": 0, "gap_tau": 6, "gap_min": 64, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "short_t": 8, "short_e": 64, "own_min": 64}
 
 
 @pytest.mark.parametrize("oi", range(len(OPTIONS)))
@@ -94,7 +96,8 @@ def test_windowed_layer_with_injected_rows(hip):
         for mdl in (MODELS[1], MODELS[4]):
             F = brute.cost_table(A, mdl, 2, NT, ST)
             scale = int(abs(F).max()) + 1
-            for w in sorted({1, 2, 3, 7, 33, n // 5, n // 2, n}):
+            # (63 .. 129: around the smallest windows the leaf pass takes -- s = 6 -- and its inner mirrored candidates [r - w, 64 g + 63 - w))
+            for w in sorted({1, 2, 3, 7, 33, 63, 64, 65, 100, 127, 128, 129, n // 5, n // 2, n}):
                 rows = [rng.integers(0, scale + 1, n + 1), np.sort(rng.integers(0, scale + 1, n + 1)), rng.integers(0, 3, n + 1),
                         np.where(rng.random(n + 1) < 0.02, 0, scale * 8).astype(np.int64)]
                 for W in rows:
