@@ -644,6 +644,9 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "nospec")) { g_opt_nospec = value; return CP_OK; }
     if (!strcmp(name, "own_min")) { g_opt_own_min = value < 64 ? 64 : value; return CP_OK; }
     if (!strcmp(name, "bn_chunk")) { g_opt_bn_chunk = value < 1 ? 1 : value; return CP_OK; }
+    if (!strcmp(name, "bn_wave")) { g_opt_bn_wave = value; return CP_OK; }
+    if (!strcmp(name, "bn_slack")) { g_opt_bn_slack = value < 0 ? 0 : value; return CP_OK; }
+    if (!strcmp(name, "bn_run")) { g_opt_bn_run = value < 2 ? 2 : value; return CP_OK; }
     set_error("unknown option");
     return CP_EINVAL;
 }

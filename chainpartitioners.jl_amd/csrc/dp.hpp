@@ -25,6 +25,7 @@ void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combin
 template <typename TC>
 void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
                          int64_t r_lo, int64_t r_hi);
+extern int64_t g_opt_bn_wave, g_opt_bn_run, g_opt_bn_slack;    // wave-per-run walk (default) and its rows per wave
 extern int64_t g_opt_bn_chunk;                 // rows per two-pointer walk (one lane each)
 
 // seq.hip

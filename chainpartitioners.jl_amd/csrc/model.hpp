@@ -27,6 +27,8 @@ template <> struct CostTraits<double> {
 // Julia Int64 arithmetic wraps; do integer adds/muls through uint64
 __host__ __device__ __forceinline__ int64_t cadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __host__ __device__ __forceinline__ double cadd(double a, double b) { return a + b; }
+__host__ __device__ __forceinline__ int64_t csub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__host__ __device__ __forceinline__ double csub(double a, double b) { return a - b; }
 __host__ __device__ __forceinline__ int64_t cmulc(int64_t cnt, int64_t b) { return (int64_t)((uint64_t)cnt * (uint64_t)b); }
 __host__ __device__ __forceinline__ double cmulc(int64_t cnt, double b) { return (double)cnt * b; }
 __host__ __device__ __forceinline__ int64_t cmulv(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }

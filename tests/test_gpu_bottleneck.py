@@ -51,13 +51,17 @@ def test_chunk_sizes_and_general_sweep_agree(hip, orc):
         K = 6
         mm = mdl.marshal()
         rc2, p2, c2 = orc.dynamic_tables(A, K, 1, mm, None)
-        for ch, dbg in ((1, 0), (3, 0), (7, 0), (16, 0), (128, 0), (100000, 0)):
-            hip.set_option("bn_chunk", ch); hip.set_option("dbg", dbg)
+        # the lane-per-chunk walk (bn_wave 0) at several chunk sizes, the wave-per-run walk (default) at several run lengths:
+        # 2 .. 64 rows = one sub-run, 65 / 127 / 253 = sub-runs anchored at their predecessor's last row, 100000 = one wave for the layer
+        # (bn_wave 2, the default: the crossings of a sub-run by binary search over windows of 64 columns -- Int64 costs; Float64 costs take the lockstep walk)
+        for wave, ch in ((0, 1), (0, 3), (0, 7), (0, 16), (0, 128), (0, 100000), (1, 2), (1, 3), (1, 63), (1, 64), (1, 65), (1, 127), (1, 253), (1, 1000), (1, 100000),
+                         (2, 2), (2, 3), (2, 63), (2, 64), (2, 65), (2, 127), (2, 253), (2, 1000), (2, 100000)):
+            hip.set_option("bn_wave", wave); hip.set_option("bn_chunk" if not wave else "bn_run", ch)
             try:
                 rc1, p1, c1 = hip.dynamic_tables(A, K, 1, mm, None)
             finally:
-                hip.set_option("bn_chunk", 8); hip.set_option("dbg", 0)
-            assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), (ch, dbg)
+                hip.set_option("bn_chunk", 8); hip.set_option("bn_run", 253); hip.set_option("bn_wave", 2)
+            assert rc1 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2), (wave, ch)
         hip.set_option("force_brute", 1)
         try:
             rc1, p1, c1 = hip.dynamic_tables(A, K, 1, mm, None)
