@@ -630,7 +630,7 @@ def main():
         elif out is not None and args.config == "3" and world == 1 and not args.no_extras:
             # driver-visible lines of the other single-GPU configs: short runs on the same resident matrix
             other = {}
-            sub = argparse.Namespace(**vars(args)); sub.steps = 2; sub.warmup = 1; sub.cpu_sizes = (2000, 4000)
+            sub = argparse.Namespace(**vars(args)); sub.steps = 5; sub.warmup = 1; sub.cpu_sizes = (2000, 4000)      # (sub-second configs: a few more steps, the clocks of a short run vary)
             B.hip.csr_destroy(B.h); del B
             torch.cuda.empty_cache()
             for c in ("constrained", "bottleneck"):

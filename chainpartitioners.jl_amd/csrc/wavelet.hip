@@ -65,7 +65,36 @@ __global__ void __launch_bounds__(256) k_wt_scatter(const int32_t *__restrict__ 
     out[np] = key;
 }
 
-void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key)
+// The key histogram of the net counter without atomics: key n - c counts the entries whose PREVIOUS occurrence lies in column c,
+// i.e. the entries OF column c that have a next occurrence (next[q] < n) -- one lane per column over its own entries; key n + 1
+// (no previous occurrence) gets what is left of N.  (The atomic histogram k_hist_keys: 17 ms at N = 10^8, a quarter of the build.)
+__global__ void __launch_bounds__(256) k_hist_net(const int64_t *__restrict__ pos, const int32_t *__restrict__ next, int64_t n, int32_t *__restrict__ hist,
+                                                  unsigned long long *__restrict__ total)
+{
+    __shared__ int32_t sh[256];
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t cnt = 0;
+    if (c < n) {
+        for (int64_t q = pos[c], q1 = pos[c + 1]; q < q1; q++) cnt += next[q] < n;
+        hist[n - c] = cnt;
+    }
+    sh[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < (unsigned)o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && sh[0]) atomicAdd(total, (unsigned long long)sh[0]);
+}
+__global__ void k_hist_net_first(int64_t N, int64_t n, const unsigned long long *__restrict__ total, int32_t *__restrict__ hist)
+{
+    hist[n + 1] = (int32_t)(N - (int64_t)*total);
+}
+// ... of the self-net counter: key n - c counts the rows whose first column is c (the buckets fpos)
+__global__ void __launch_bounds__(256) k_hist_self(const int64_t *__restrict__ fpos, int64_t n, int32_t *__restrict__ hist)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) hist[n - c] = (int32_t)(fpos[c + 1] - fpos[c]);
+}
+
+void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key, const WaveletHist *pre)
 {
     ProfScope ps(PROF_WAVELET, s, 8.0 * (double)Nk * (double)H);
     int64_t W = 1 + cdiv(Nk, 64);
@@ -79,7 +108,14 @@ void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, 
     DBuf<int32_t> hist((size_t)nkeys), popc((size_t)W), tmp((size_t)(Nk > 0 ? Nk : 1));
     DBuf<int64_t> scratch;
     CP_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), s));
-    if (Nk > 0) hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p, hot_key);
+    DBuf<unsigned long long> total(1);
+    if (pre && pre->kind == 1 && Nk > 0) {
+        CP_HIP(hipMemsetAsync(total.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_hist_net, dim3((unsigned)cdiv(pre->n, 256)), dim3(256), 0, s, pre->pos, pre->link, pre->n, hist.p, total.p);
+        hipLaunchKernelGGL(k_hist_net_first, dim3(1), dim3(1), 0, s, Nk, pre->n, total.p, hist.p);
+    } else if (pre && pre->kind == 2 && Nk > 0) {
+        hipLaunchKernelGGL(k_hist_self, dim3((unsigned)cdiv(pre->n, 256)), dim3(256), 0, s, pre->pos, pre->n, hist.p);
+    } else if (Nk > 0) hipLaunchKernelGGL(k_hist_keys, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, keys.p, Nk, hist.p, hot_key);
     exclusive_scan_i32_i32(hist.p, WT.qos0.p, nkeys, scratch, s);
     int32_t *cur = keys.p, *oth = tmp.p;
     for (int h = H; h >= 1 && Nk > 0; h--) {
@@ -306,7 +342,8 @@ void ensure_net_counter(cp_csr_s *A, WaveletHost &out)
     int64_t N = A->N;
     DBuf<int32_t> keys((size_t)(N > 0 ? N : 1));
     if (N > 0) hipLaunchKernelGGL(k_keys_net, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, A->prev.p, keys.p, N, (int32_t)A->n);
-    wavelet_build(out, keys, N, cllog2_i(A->n + 2), s, (int32_t)(A->n + 1));      // key n + 1: the first occurrence of a row
+    const WaveletHist pre{1, A->n, A->pos.p, A->next.p};                           // (the key histogram straight from the columns: no atomics)
+    wavelet_build(out, keys, N, cllog2_i(A->n + 2), s, (int32_t)(A->n + 1), &pre);      // key n + 1: the first occurrence of a row
 }
 void ensure_selfnet_counter(cp_csr_s *A, WaveletHost &out)
 {
@@ -315,7 +352,8 @@ void ensure_selfnet_counter(cp_csr_s *A, WaveletHost &out)
     int64_t Np = A->nrows_nonempty;
     DBuf<int32_t> keys((size_t)(Np > 0 ? Np : 1));
     if (Np > 0) hipLaunchKernelGGL(k_keys_self, dim3((unsigned)cdiv(Np, 256)), dim3(256), 0, s, A->lfirst.p, keys.p, Np, (int32_t)A->n);
-    wavelet_build(out, keys, Np, cllog2_i(A->n + 2), s);
+    const WaveletHist pre{2, A->n, A->fpos.p, nullptr};
+    wavelet_build(out, keys, Np, cllog2_i(A->n + 2), s, -1, &pre);
 }
 
 // queries are 1-based like the reference: DOM C[i,j]; NET / SELFNET [j, j']

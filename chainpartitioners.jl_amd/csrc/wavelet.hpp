@@ -51,7 +51,10 @@ struct WaveletHost {
 };
 
 // keys: device int32 array of Nk values in [0, 2^H); destroyed (used as scratch)
-void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key = -1);      // hot_key: a key many entries share (counted per wave)
+// the key histogram from the pattern instead of from the keys (no atomics): kind 1 = net counter (pos = colptr, link = next),
+// kind 2 = self-net counter (pos = rows bucketed by first column)
+struct WaveletHist { int kind; int64_t n; const int64_t *pos; const int32_t *link; };
+void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, hipStream_t s, int32_t hot_key = -1, const WaveletHist *pre = nullptr);      // hot_key: a key many entries share (counted per wave)
 
 }  // namespace cpk
 
