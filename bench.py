@@ -454,8 +454,39 @@ def run_cfg2(args, dev, brief=False):
         rc, lo, hi = hip.bound_stripe(h, K, mm)
         assert lo <= obj <= hi                                               # the bounds sandwich of test_Costs.jl
         res[name] = {"ms_per_step": t * 1e3, "bottleneck": int(obj), "bound_stripe": [int(lo), int(hi)]}
+    # ---- a batch: 256 requests (K x eps x model constants) on the same pattern in ONE launch (cp_partition_bisect_cost_batch): the probe
+    # chain of one partition fills one wave; a sweep fills the chip and shares the counting structure
+    breq = []
+    for Kb in (8, 16, 32, 64, 128, 256, 512, 1024):
+        for eps in (0.1, 0.03, 0.01, 0.003):
+            for mdl in (cp.AffineWorkModel(0, 10, 1), cp.AffineWorkModel(0, 1, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineConnectivityModel(0, 0, 0, 1),
+                        cp.AffineConnectivityModel(0, 1, 1, 10), cp.AffineConnectivityModel(5, 10, 1, 100), cp.AffineConnectivityModel(0, 3, 1, 30), cp.AffineConnectivityModel(0, 100, 1, 1000)):
+                breq.append((Kb, mdl, eps))
+    bmms = [m.marshal() for _, m, _ in breq]
+
+    def run_batch():
+        hip.reset_cache(h)
+        rc, spls = hip.partition_bisect_cost_batch(h, [k for k, _, _ in breq], bmms, [e for _, _, e in breq], [0] * len(breq))
+        assert rc == 0, hip.last_error()
+        return spls
+    bspl = run_batch()
+    tb = timed(run_batch, max(args.steps, 3))
+    # the same requests one by one (what a loop over cp_partition_bisect_cost costs, structures rebuilt per call as a reference call does)
+    def run_loop():
+        for (kb, _, e), mm in list(zip(breq, bmms))[:32]:
+            hip.reset_cache(h)
+            sp = np.zeros(kb + 1, dtype=np.int64)
+            assert hip.partition_bisect_cost(h, kb, mm, e, 0, sp) == 0
+    run_loop()
+    tl = timed(run_loop, 1) / 32
+    for i in (0, 37, 101, 255):                              # spot check against the single call
+        kb, _, e = breq[i]
+        sp = np.zeros(kb + 1, dtype=np.int64)
+        assert hip.partition_bisect_cost(h, kb, bmms[i], e, 0, sp) == 0 and np.array_equal(sp, bspl[i]), i
+    batch = {"batch": len(breq), "ms_total": tb * 1e3, "ms_per_problem": tb * 1e3 / len(breq), "ms_per_problem_one_by_one": tl * 1e3,
+             "requests": "K in {8..1024} x eps in {0.1, 0.03, 0.01, 0.003} x 8 Work / Connectivity models; link arrays + ONE net counter included"}
     hip.csr_destroy(h)
-    info = {"n": n, "nnz": N, "K": K, "eps": 0.01, "results": res}
+    info = {"n": n, "nnz": N, "K": K, "eps": 0.01, "results": res, "batch": batch}
     if brief:
         return info
     # CPU baseline: the oracle's BisectCost directly at full size
@@ -476,6 +507,16 @@ def run_cfg2(args, dev, brief=False):
         assert np.array_equal(P.spl, spl), "GPU and oracle split vectors differ at full size"
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "partitions/s", "cores": 1, "kind": "port",
                                "sample": "the oracle's BisectCost at the full size n=%d (direct; same split vector as the GPU)" % n, "host_cores": os.cpu_count()}
+        # the batch against the oracle: four of its requests, timed one by one (each builds its own structures, as a reference call does)
+        tcb = 0.0
+        for i in (3, 66, 130, 250):
+            kb, mdl, e = breq[i]
+            t0 = time.perf_counter()
+            P = cp.partition_stripe(A, kb, cp.BisectCostBottleneckSplitter(mdl, e), backend=orc)
+            tcb += time.perf_counter() - t0
+            assert np.array_equal(P.spl, bspl[i]), "batch and oracle split vectors differ (request %d)" % i
+        batch["oracle_ms_per_problem"] = tcb / 4 * 1e3
+        batch["speedup_per_problem_vs_oracle_1_core"] = (tcb / 4) / (tb / len(breq))
     return out
 
 
@@ -525,6 +566,28 @@ def run_cfg4(args, dev):
                         "frac": (8.0 * (n + 1 + N) + 24.0 * (n + 1)) / times["convex"] / 1e9 / HBM_PEAK_GBS, "traffic": None},
            "check": {"K_convex": len(out_spl["convex"]) - 1, "K_dynamic": len(out_spl["dynamic"]) - 1, "total_value": value,
                      "dynamic_total_chunker_ms": times["dynamic"] * 1e3}}
+    # ---- a batch: requests (cost constants x width limits) on the same pattern in ONE launch (cp_pack_convex_batch), one wave each
+    nb = args.batch
+    bmeth = []
+    for i in range(nb):
+        a = 1 + i % 16
+        w = 4 + (i // 16) % 5                                # widths 4 .. 8
+        bmeth.append((cp.ColumnBlockComponentCostModel(a, lambda x: 1 + x), w))
+    bmms = [api._marshal(proxy, cp.ConstrainedCost(m, cp.VertexCount(), w), None, stack_method=True)[1] for m, w in bmeth]
+    hip.reset_cache(h)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc, bspl = hip.pack_convex_batch(h, bmms, [w for _, w in bmeth], n)
+    tb = time.perf_counter() - t0
+    assert rc == 0, hip.last_error()
+    for (m, w), sp in zip(bmeth, bspl):
+        assert sp[0] == 1 and sp[-1] == n + 1 and int(np.diff(sp).max()) <= w
+    i0 = 4 * 16 + 2                                          # a = 1 + i % 16 = 3, w = 4 + i // 16 = 8: the request of the single call above
+    if i0 < nb:
+        assert np.array_equal(bspl[i0], out_spl["convex"]), "the batch's request (3, w -> 1 + w, 8) differs from the single call"
+    out["check"]["batch"] = {"batch": nb, "s_total": tb, "ms_per_problem": tb * 1e3 / nb,
+                             "requests": "ColumnBlockComponentCostModel(a, w -> 1 + w), a in 1..16, VertexCount limits 4..8; link arrays, ONE net counter, ONE table of net counts, "
+                                         "the copies of the chunk vectors to the host and their unravelling included"}
     if not args.no_cpu_baseline:
         orc = oracle_backend()
         A = cp.SparseMatrixCSC(n, n, colptr.cpu().numpy(), rowval.cpu().numpy())
@@ -534,6 +597,15 @@ def run_cfg4(args, dev):
         assert np.array_equal(P.spl, out_spl["convex"]), "GPU and oracle chunk vectors differ at full size"
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "partitions/s", "cores": 1, "kind": "port", "seconds": tc,
                                "sample": "the oracle's ConvexTotalChunker at the full size n=%d (direct; identical chunk vector)" % n, "host_cores": os.cpu_count()}
+        # one more request of the batch against the oracle
+        ib = min(nb - 1, 7 * 16 + 5)
+        mb, wb = bmeth[ib]
+        t0 = time.perf_counter()
+        Pb = cp.pack_stripe(A, cp.ConvexTotalChunker(cp.ConstrainedCost(mb, cp.VertexCount(), wb)), backend=orc)
+        tcb = time.perf_counter() - t0
+        assert np.array_equal(Pb.spl, bspl[ib]), "batch and oracle chunk vectors differ"
+        out["check"]["batch"]["oracle_s_per_problem"] = (tc + tcb) / 2
+        out["check"]["batch"]["speedup_per_problem_vs_oracle_1_core"] = ((tc + tcb) / 2) / (tb / nb)
     hip.csr_destroy(h)
     return out
 
@@ -579,6 +651,7 @@ def main():
     ap.add_argument("--mode", choices=["independent", "tiled"], default="independent",
                     help="N>1: 'independent' = one partition per GPU (weak scaling, `value`) followed by ONE row-tiled partition in "
                          "extras.tiled (strong scaling); 'tiled' = `value` itself is the row-tiled partition (RCCL all_gather per layer)")
+    ap.add_argument("--batch", type=int, default=256, help="config 4: requests of the batched ConvexTotalChunker line")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: only with --dry-run")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + collectives without GPU work (tests)")
     ap.add_argument("--emit-spl", action="store_true", help="put rank 0's split vector into check.spl (parity tests at small n)")

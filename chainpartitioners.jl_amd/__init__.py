@@ -18,6 +18,6 @@ from .models import (PowerWorkModel, ConvexWorkModel, ConcaveWorkModel,   # noqa
                      AlternatingNetPartitioner, SymmetricPartitioner,
                      ConvexTotalChunker, ConvexTotalSplitter, ConcaveTotalChunker, ConcaveTotalSplitter)
 from . import _lib  # noqa: F401
-from .api import (adjointpattern, partition_plaid, partition_stripe, pack_stripe, oracle_stripe, bound_stripe, total_value,   # noqa: F401
+from .api import (adjointpattern, partition_plaid, partition_stripe, partition_stripe_batch, pack_stripe, pack_stripe_batch, oracle_stripe, bound_stripe, total_value,   # noqa: F401
                   bottleneck_value, netcount, selfnetcount, dominancecount, set_default_backend,
                   get_backend, CPError, Step, Same, Next, Prev, Jump)

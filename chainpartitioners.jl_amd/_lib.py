@@ -20,7 +20,7 @@ SYMBOLS = [
     "cp_last_error", "cp_version", "cp_device_count", "cp_csr_create", "cp_csr_create_device", "cp_csr_destroy",
     "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise", "cp_domsum_build", "cp_rook_build", "cp_wsum_query", "cp_wsum_destroy",
     "cp_oracle_eval", "cp_oracle_step", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
-    "cp_partition_bisect_cost", "cp_pack_convex", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
+    "cp_partition_bisect_cost", "cp_partition_bisect_cost_batch", "cp_pack_convex", "cp_pack_convex_batch", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
     "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_reset_stream", "cp_get_stat", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window", "cp_dp_set_rows",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
@@ -161,6 +161,18 @@ class HipBackend:
         return self.lib.cp_partition_bisect_cost_pi(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
                                                     C.c_double(eps), C.c_int32(flip), _p(spl))
 
+    def partition_bisect_cost_batch(self, A, Ks, mms, epss, flips):
+        """B requests on one pattern in one launch -> (rc, [split vector of request b])"""
+        B = len(Ks)
+        arr = (M.cp_model_t * B)(*[m.struct for m in mms])          # (struct copies; the buffers they point into live in `mms`)
+        Kv = np.ascontiguousarray(Ks, dtype=np.int64)
+        ev = np.ascontiguousarray(epss, dtype=np.float64)
+        fv = np.ascontiguousarray(flips, dtype=np.int32)
+        ld = int(Kv.max()) + 1
+        out = np.zeros((B, ld), dtype=np.int64)
+        rc = self.lib.cp_partition_bisect_cost_batch(self._h(A), _i64(B), _p(Kv), arr, _p(ev), _p(fv), _i64(ld), _p(out))
+        return rc, [out[b, :int(Kv[b]) + 1].copy() for b in range(B)]
+
     def partition_bisect_index(self, A, K, mm, flip, spl, rp=None):
         return self.lib.cp_partition_bisect_index_pi(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,
                                                      C.c_int32(flip), _p(spl))
@@ -171,6 +183,17 @@ class HipBackend:
     def pack_convex(self, A, mm, rp, wm, wi, wf, spl, Kout):
         return self.lib.cp_pack_convex(self._h(A), mm.ptr, C.byref(rp) if rp is not None else None,
                                        wm.ptr if wm is not None else None, _i64(wi), C.c_double(wf), _p(spl), _p(Kout))
+
+    def pack_convex_batch(self, A, mms, wmaxs, n):
+        """B requests (model, w_max) on one pattern in one launch -> (rc, [chunk boundaries of request b])"""
+        B = len(mms)
+        arr = (M.cp_model_t * B)(*[m.struct for m in mms])
+        wv = np.ascontiguousarray(wmaxs, dtype=np.int64)
+        ld = int(n) + 1
+        out = np.zeros((B, ld), dtype=np.int64)
+        Kout = np.zeros(B, dtype=np.int64)
+        rc = self.lib.cp_pack_convex_batch(self._h(A), _i64(B), arr, _p(wv), _i64(ld), _p(out), _p(Kout))
+        return rc, [out[b, :int(Kout[b]) + 1].copy() for b in range(B)]
 
     def partition_convex(self, A, K, mm, rp, wm, wi, wf, spl):
         return self.lib.cp_partition_convex(self._h(A), _i64(K), mm.ptr, C.byref(rp) if rp is not None else None,

@@ -170,6 +170,50 @@ def partition_stripe(A: SparseMatrixCSC, K, method, Pi=None, *, backend=None) ->
     raise NotImplementedError(f"partition_stripe: method {type(method).__name__} is outside the hot path")
 
 
+def partition_stripe_batch(A: SparseMatrixCSC, requests, *, backend=None):
+    """[partition_stripe(A, K, method) for (K, method) in requests] in ONE device launch, for the methods whose single partition is a
+    sequential chain on one wave: BisectCostBottleneckSplitter(f, eps) with Work / Connectivity costs (a sweep over K, eps and the
+    model constants; BisectCostBottleneckSplitter.jl:6-63 per request).  The reference has no batch call -- it would loop; the
+    results are those of the loop."""
+    b = get_backend(backend)
+    if not requests:
+        return []
+    if not all(isinstance(m, M.BisectCostBottleneckSplitter) for _, m in requests):
+        raise NotImplementedError("partition_stripe_batch takes BisectCostBottleneckSplitter requests")
+    if not hasattr(b, "partition_bisect_cost_batch"):
+        return [partition_stripe(A, K, m, backend=b) for K, m in requests]
+    mms = []
+    for K, m in requests:
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, m.f, None)
+        if wm is not None:
+            raise NotImplementedError("BisectCost on a ConstrainedCost errors in the reference (Costs.jl:150)")
+        mms.append(mm)
+    rc, spls = b.partition_bisect_cost_batch(A, [int(K) for K, _ in requests], mms, [m.eps for _, m in requests], [int(m.flip) for _, m in requests])
+    _check(rc, "partition_stripe_batch(BisectCost)", b)
+    return [SplitPartition(int(K), s) for (K, _), s in zip(requests, spls)]
+
+
+def pack_stripe_batch(A: SparseMatrixCSC, methods, *, backend=None):
+    """[pack_stripe(A, method) for method in methods] in ONE device launch for ConvexTotalChunker(ConstrainedCost(f, VertexCount(), w))
+    requests with 1 <= w <= 15 and ColumnBlock / Connectivity / Work costs (ConvexTotalChunker.jl:141-168, 211-265 per request): a sweep
+    over the cost constants and width limits.  The results are those of the loop."""
+    b = get_backend(backend)
+    if not methods:
+        return []
+    ok = all(isinstance(m, M.ConvexTotalChunker) and isinstance(M.split_constraint(m.f)[1], M.VertexCount) for m in methods)
+    if not ok:
+        raise NotImplementedError("pack_stripe_batch takes ConvexTotalChunker(ConstrainedCost(f, VertexCount(), w)) requests")
+    if not hasattr(b, "pack_convex_batch"):
+        return [pack_stripe(A, m, backend=b) for m in methods]
+    mms, ws = [], []
+    for m in methods:
+        mdl, mm, wm, wi, wf, rp, keep = _marshal(A, m.f, None, stack_method=True)
+        mms.append(mm); ws.append(int(wi))
+    rc, spls = b.pack_convex_batch(A, mms, ws, A.n)
+    _check(rc, "pack_stripe_batch(ConvexTotalChunker)", b)
+    return [SplitPartition(len(s) - 1, s) for s in spls]
+
+
 # ---------------------------------------------------------------- pack_stripe
 def pack_stripe(A: SparseMatrixCSC, method, Pi=None, *, backend=None) -> SplitPartition:
     if isinstance(method, M.EquiChunker):

@@ -118,9 +118,9 @@ __device__ int64_t search6(const OracleDev<TC> &O, int64_t j, int64_t lo, int64_
 }
 
 template <typename TC>
-__global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, double c_lo, double c_hi, double eps, int flip,
-                                               int64_t *__restrict__ spl_lo, int64_t *__restrict__ spl_hi, int64_t *__restrict__ spl,
-                                               int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
+__device__ __forceinline__ void bisect_cost_body(const OracleDev<TC> &O, int64_t K, double c_lo, double c_hi, double eps, int flip,
+                                                 int64_t *__restrict__ spl_lo, int64_t *__restrict__ spl_hi, int64_t *__restrict__ spl,
+                                                 int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
 {
     int lane = threadIdx.x;
     int64_t n = O.n;
@@ -165,6 +165,29 @@ __global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, doubl
     const int64_t *src = flip ? spl_lo : spl_hi;
     for (int64_t k = lane; k <= K; k += 64) out[k] = src[k];
     if (lane == 0) *nprobes = stuck ? -1 : probes;
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_bisect(OracleDev<TC> O, int64_t K, double c_lo, double c_hi, double eps, int flip,
+                                               int64_t *__restrict__ spl_lo, int64_t *__restrict__ spl_hi, int64_t *__restrict__ spl,
+                                               int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
+{
+    bisect_cost_body<TC>(O, K, c_lo, c_hi, eps, flip, spl_lo, spl_hi, spl, out, nprobes);
+}
+
+// B independent requests (K, model, eps, flip) on ONE pattern, one wave each: the sequential probe chain of a single partition
+// leaves 255 of 256 CUs idle -- a sweep over K / eps / model constants fills them, and the counting structure is built once
+template <typename TC>
+struct BisectReq { DevModel<TC> M; int64_t K; double c_lo, c_hi, eps; int32_t flip, _pad; };
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_bisect_batch(OracleDev<TC> O, const BisectReq<TC> *__restrict__ req, int64_t ld, int64_t *__restrict__ work,
+                                                     int64_t *__restrict__ out, int64_t *__restrict__ nprobes)
+{
+    const BisectReq<TC> R = req[blockIdx.x];
+    O.M = R.M;
+    int64_t *w = work + (int64_t)blockIdx.x * 3 * ld;
+    bisect_cost_body<TC>(O, R.K, R.c_lo, R.c_hi, R.eps, R.flip, w, w + ld, w + 2 * ld, out + (int64_t)blockIdx.x * ld, nprobes + blockIdx.x);
 }
 
 // ------------------------------------------------------------------ BisectIndexBottleneckSplitter.jl:5-83, flip :85-166
@@ -312,9 +335,67 @@ int32_t run_bisect(cp_csr_s *A, int64_t K, const cp_model_t *mdl, const cp_rowpa
     return CP_OK;
 }
 
+template <typename TC>
+int32_t run_bisect_batch(cp_csr_s *A, int64_t B, const int64_t *K, const cp_model_t *models, const double *eps, const int32_t *flip, int64_t ld,
+                         int64_t *spl_out)
+{
+    hipStream_t s = A->stream;
+    std::vector<HostModel<TC>> HM((size_t)B);
+    std::vector<BisectReq<TC>> req((size_t)B);
+    bool any_net = false;
+    for (int64_t b = 0; b < B; b++) {
+        const cp_model_t *m = models + b;
+        build_dev_model<TC>(m, HM[(size_t)b], s);
+        int64_t li, hi; double lf, hf;
+        int32_t rc = cp_bound_stripe(A, K[b], m, &li, &hi, &lf, &hf);      // (c_lo, c_hi) = bound_stripe(A, K, f) ./ 1  (BisectCostBottleneckSplitter.jl:39)
+        if (rc != CP_OK) return rc;
+        BisectReq<TC> &R = req[(size_t)b];
+        memset(&R, 0, sizeof(R));
+        R.M = HM[(size_t)b].d; R.K = K[b]; R.c_lo = lf; R.c_hi = hf; R.eps = eps[b]; R.flip = flip ? flip[b] : 0;
+        any_net |= m->kind == CP_MODEL_CONNECTIVITY;
+    }
+    OracleDev<TC> O;
+    memset(&O, 0, sizeof(O));
+    O.pos = A->pos.p; O.n = A->n;
+    WaveletHost net;
+    if (any_net) { ensure_net_counter(A, net); O.has_net = 1; O.net = net.d; }      // built ONCE for the whole batch
+    DBuf<BisectReq<TC>> dreq((size_t)B);
+    DBuf<int64_t> work((size_t)(3 * B * ld)), out((size_t)(B * ld)), np((size_t)B);
+    CP_HIP(hipMemcpyAsync(dreq.p, req.data(), sizeof(BisectReq<TC>) * (size_t)B, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(PROF_BISECT, s, 0.0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bisect_batch<TC>), dim3((unsigned)B), dim3(64), 0, s, O, dreq.p, ld, work.p, out.p, np.p);
+    }
+    CP_HIP(hipGetLastError());
+    std::vector<int64_t> hnp((size_t)B);
+    CP_HIP(hipMemcpyAsync(spl_out, out.p, sizeof(int64_t) * (size_t)(B * ld), hipMemcpyDeviceToHost, s));
+    CP_HIP(hipMemcpyAsync(hnp.data(), np.p, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    for (int64_t b = 0; b < B; b++)
+        CP_REQUIRE(hnp[(size_t)b] >= 0, CP_EINVAL, "cost bisection cannot terminate on these bounds (the reference loops forever: non-positive costs)");
+    return CP_OK;
+}
+
 }  // namespace cpk
 
 using namespace cpk;
+
+extern "C" int32_t cp_partition_bisect_cost_batch(cp_csr_t A, int64_t B, const int64_t *K, const cp_model_t *models, const double *eps,
+                                                  const int32_t *flip, int64_t ld, int64_t *spl_out)
+{
+    try {
+        CP_REQUIRE(A && K && models && eps && spl_out && B >= 1 && B <= 65535, CP_EINVAL, "bad argument");
+        for (int64_t b = 0; b < B; b++) {
+            CP_REQUIRE(K[b] >= 1 && K[b] + 1 <= ld, CP_EINVAL, "every request needs 1 <= K and K + 1 <= ld");
+            CP_REQUIRE((models[b].kind == CP_MODEL_WORK || models[b].kind == CP_MODEL_CONNECTIVITY) && models[b].dtype == models[0].dtype, CP_EUNSUPPORTED,
+                       "a batch takes Work / Connectivity models of one element type");
+        }
+        CP_HIP(hipSetDevice(A->device));
+        if (models[0].dtype == CP_I64) return run_bisect_batch<int64_t>(A, B, K, models, eps, flip, ld, spl_out);
+        return run_bisect_batch<double>(A, B, K, models, eps, flip, ld, spl_out);
+    } CP_CATCH_ALL
+}
 
 extern "C" int32_t cp_partition_bisect_cost_pi(cp_csr_t A, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, double eps,
                                                int32_t flip, int64_t *spl_out)

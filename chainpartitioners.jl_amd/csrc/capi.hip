@@ -356,6 +356,27 @@ static bool windowed_ok(cp_csr_s *A, int64_t K, int32_t combine, const cp_model_
            fast_total_ok(model, A->n, A->N, K);
 }
 
+// A weight that is a function of the WIDTH only -- VertexCount(), or AffineWorkModel(alpha, c, 0) with c > 0 (the reference's own
+// tests constrain with AffineWorkModel(0, 1, 0), test/test_Partitioners.jl:178-183,256-261) -- bounds the parts by a number of
+// columns: the largest nv with w(nv) = alpha + nv c <= w_max, evaluated in the weight's own arithmetic and order (WorkCosts.jl:17;
+// the pin term is nv * 0 = 0).  -> that width (0: only empty parts fit, -1: not even those), or -2: not a width weight.
+static int64_t width_of_weight(const cp_model_t *w, int64_t n, int64_t wmax_i64, double wmax_f64)
+{
+    if (!w) return -2;
+    if (w->kind == CP_MODEL_VERTEX_COUNT) return wmax_i64;
+    if (w->kind != CP_MODEL_WORK || w->alpha_k) return -2;
+    auto fits_i = [&](int64_t nv) { return cadd(cadd(w->p_i64[CP_P_ALPHA], cmulc(nv, w->p_i64[CP_P_VERTEX])), cmulc((int64_t)0, w->p_i64[CP_P_PIN])) <= wmax_i64; };
+    auto fits_f = [&](int64_t nv) { return cadd(cadd(w->p_f64[CP_P_ALPHA], cmulc(nv, w->p_f64[CP_P_VERTEX])), cmulc((int64_t)0, w->p_f64[CP_P_PIN])) <= wmax_f64; };
+    const bool is_i = w->dtype == CP_I64;
+    if (is_i ? !(w->p_i64[CP_P_PIN] == 0 && w->p_i64[CP_P_VERTEX] > 0) : !(w->p_f64[CP_P_PIN] == 0.0 && w->p_f64[CP_P_VERTEX] > 0.0)) return -2;
+    auto fits = [&](int64_t nv) { return is_i ? fits_i(nv) : fits_f(nv); };
+    if (!fits(0)) return -1;
+    int64_t lo = 0, hi = n + 1;                       // fits(lo); the weight grows with nv: the largest nv <= n + 1 that fits
+    if (fits(hi)) return hi;
+    while (hi - lo > 1) { const int64_t mid = lo + ((hi - lo) >> 1); if (fits(mid)) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // ------------------------------------------------------------------ row-tiled DP (one rank = one tile of rows per layer)
 // cp_dp_*: the same layers as run_dynamic, but a rank computes only rows [row_lo, row_hi) of every layer and the caller
 // completes the layer's cost vector with a collective (RCCL all_gather over xGMI) before the next layer.
@@ -701,9 +722,12 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
         if (constrained) {
             CP_REQUIRE(weight->kind == CP_MODEL_VERTEX_COUNT || (weight->kind == CP_MODEL_WORK && !weight->alpha_k), CP_EINVAL,
                        "weight must be VertexCount or an AffineWorkModel");
-            if (windowed_ok(A, K, combine, model, weight, wmax_i64)) {      // O(K n log^2 n): the windowed geometry of dp_total.hip
-                if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wmax_i64, spl_out, nullptr, nullptr, nullptr, nullptr);
-                return run_dynamic_windowed<double>(A, K, order, model, wmax_i64, spl_out, nullptr, nullptr, nullptr, nullptr);
+            // width weights (VertexCount, AffineWorkModel(alpha, c, 0)): the equivalent number of columns
+            const int64_t wv = width_of_weight(weight, A->n, wmax_i64, wmax_f64);
+            cp_model_t vc{}; vc.kind = CP_MODEL_VERTEX_COUNT; vc.dtype = CP_I64;
+            if (wv >= 1 && windowed_ok(A, K, combine, model, &vc, wv)) {      // O(K n log^2 n): the windowed geometry of dp_total.hip
+                if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr);
+                return run_dynamic_windowed<double>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr);
             }
             if (model->dtype == CP_I64) return run_dyn_constrained<int64_t>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
             return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);

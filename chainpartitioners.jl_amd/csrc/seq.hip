@@ -446,14 +446,28 @@ __device__ __forceinline__ void cw_chunk_convex(CwState<TC> &S, const CwEnv &E, 
 #undef CW_F
 }
 
-template <typename TC>
-__global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int32_t w, int64_t *__restrict__ ptr, int32_t *__restrict__ status,
-                                                        const SeqOracle<TC> *__restrict__ Odev)
+// where the window-table entry F[j'][d] = f(j' - d, j') comes from: the request's own table, or (batches: B requests on one
+// pattern) a SHARED table of net counts that the request's model turns into a cost on the way into LDS
+template <typename TC> struct CwTabF {
+    const TC *__restrict__ F; int32_t FW;
+    __device__ __forceinline__ TC operator()(int32_t row, int32_t d) const { return F[(int64_t)row * FW + d]; }
+};
+template <typename TC> struct CwTabNets {
+    const int32_t *__restrict__ NT; int32_t FW; const int64_t *__restrict__ pos; DevModel<TC> M; TC alpha;
+    __device__ __forceinline__ TC operator()(int32_t row, int32_t d) const
+    {
+        const int32_t p = row - 1 - d;                                   // 0-based first column of the part [j' - d, j')
+        if (p < 0) return (TC)0;                                         // (outside the matrix: never evaluated)
+        return dm_apply(M, alpha, (int64_t)d, pos[row - 1] - pos[p], (int64_t)NT[(int64_t)row * FW + d], (int64_t)0);
+    }
+};
+
+template <typename TC, typename TAB>
+__device__ __forceinline__ void cw_pack_body(CwState<TC> &S, const TAB Ftab_at, int32_t n, int32_t Wc, int32_t w, int64_t *__restrict__ ptr,
+                                             int32_t *__restrict__ status, const SeqOracle<TC> *__restrict__ Odev)
 {
-    __shared__ CwState<TC> S;
     const int lane = threadIdx.x;
-    const int32_t n = (int32_t)Oarg.n, Jp1 = n + 1, Wc = (int32_t)Oarg.Wc, FWg = Wc + 1;
-    const TC *__restrict__ Ftab = Oarg.Ftab;
+    const int32_t Jp1 = n + 1, FWg = Wc + 1;
     // ptr[] starts at zeros(Ti, n + 1) (:151): filled by the whole wave
     for (int64_t t = lane; t <= (int64_t)n + 1; t += 64) ptr[t] = 0;
     CwEnv E; E.n = n; E.Wc = Wc; E.mode = 0; E.I = 0;
@@ -464,7 +478,7 @@ __global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int3
     if (hi_res > Jp1) hi_res = Jp1;
     for (int32_t e = lane; e < hi_res * FWg; e += 64) {
         const int32_t row = 1 + e / FWg, d = e - (row - 1) * FWg;
-        S.F[row & (CW_RING - 1)][d] = Ftab[(int64_t)row * FWg + d];
+        S.F[row & (CW_RING - 1)][d] = Ftab_at(row, d);
     }
     S.cst[1] = ext_of((TC)0);                                         // cst[1] = zero (:152)
     __syncthreads();
@@ -486,7 +500,7 @@ __global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int3
         for (int k = 0; k < 8; k++) {
             const int32_t e = lane + 64 * k;
             pre[k] = (TC)0;
-            if (e < nx_cnt) { const int32_t ro = e / FWg, d = e - ro * FWg; pre[k] = Ftab[(int64_t)(E.hi_res + 1 + ro) * FWg + d]; }
+            if (e < nx_cnt) { const int32_t ro = e / FWg, d = e - ro * FWg; pre[k] = Ftab_at(E.hi_res + 1 + ro, d); }
         }
         cw_chunk_convex<TC, 0>(S, E, Odev, ptr, j0, jp1);
         if (jp1 == Jp1) break;
@@ -515,6 +529,50 @@ __global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int3
         E.lo_res = j0;
     }
     if (lane == 0) *status = rc;
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_convex_win(SeqOracle<TC> Oarg, int32_t w, int64_t *__restrict__ ptr, int32_t *__restrict__ status,
+                                                        const SeqOracle<TC> *__restrict__ Odev)
+{
+    __shared__ CwState<TC> S;
+    const CwTabF<TC> T{Oarg.Ftab, (int32_t)Oarg.Wc + 1};
+    cw_pack_body<TC>(S, T, (int32_t)Oarg.n, (int32_t)Oarg.Wc, w, ptr, status, Odev);
+}
+
+// B requests (model, w_max) on ONE pattern, one wave (workgroup) each: the stack algorithm is a dependent chain that fills one wave
+// however long the matrix is, so a sweep over the cost constants / widths fills the chip.  The requests share the table of net
+// counts NT[j'][d] = nets(j' - d, j') (stride FWs, built once); request b applies its own model while the rows enter LDS.
+template <typename TC>
+struct CwReq { DevModel<TC> M; TC alpha; int32_t w, _pad; int64_t *ptr; };
+
+template <typename TC>
+__global__ void __launch_bounds__(64) k_pack_convex_win_batch(const CwReq<TC> *__restrict__ req, const SeqOracle<TC> *__restrict__ Odev, int32_t n,
+                                                              const int32_t *__restrict__ NT, int32_t FWs, const int64_t *__restrict__ pos,
+                                                              int32_t *__restrict__ status)
+{
+    __shared__ CwState<TC> S;
+    const CwReq<TC> R = req[blockIdx.x];
+    const CwTabNets<TC> T{NT, FWs, pos, R.M, R.alpha};
+    cw_pack_body<TC>(S, T, n, 2 * R.w + 2, R.w, R.ptr, status + blockIdx.x, Odev + blockIdx.x);
+}
+
+// the shared table of a batch: nets(j' - d, j') for d <= Wc, one thread per j' (the walk of k_window_table without a model)
+__global__ void __launch_bounds__(256) k_window_nets(int64_t n, int64_t Wc, const int64_t *__restrict__ pos, const int32_t *__restrict__ next,
+                                                     int32_t *__restrict__ NT)
+{
+    const int64_t jp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (jp > n + 1) return;
+    const int64_t r = jp - 1;
+    int32_t *row = NT + jp * (Wc + 1);
+    int32_t nn = 0;
+    row[0] = 0;
+    for (int64_t d = 1; d <= Wc; d++) {
+        const int64_t p = r - d;
+        if (p < 0) { row[d] = 0; continue; }
+        for (int64_t q = pos[p]; q < pos[p + 1]; q++) nn += (next[q] >= (int32_t)r);
+        row[d] = nn;
+    }
 }
 
 // ------------------------------------------------------------------ ConcaveTotalChunker.jl
@@ -974,6 +1032,66 @@ int32_t run_pack_convex(cp_csr_s *A, const cp_model_t *mdl, const cp_rowpart_t *
     return CP_OK;
 }
 
+// pack_stripe(A, ConvexTotalChunker(ConstrainedCost(f_b, VertexCount(), w_b))) for B requests on one pattern: ONE launch, the net
+// counter and the window table of net counts built once.  Every request must be one the LDS kernel takes on its own (width weight,
+// 1 <= w <= CW_MAXW, a net-count model without per-part alpha); the results are those of B single calls.
+template <typename TC>
+int32_t run_pack_convex_batch(cp_csr_s *A, int64_t B, const cp_model_t *models, const int64_t *wmax, int64_t ld, int64_t *spl_out, int64_t *K_out)
+{
+    hipStream_t s = A->stream;
+    const int64_t n = A->n;
+    int64_t wall = 1;
+    for (int64_t b = 0; b < B; b++) wall = std::max(wall, wmax[b]);
+    const int64_t Wc = 2 * wall + 2, FWs = Wc + 1;
+    ensure_links(A);
+    std::vector<std::unique_ptr<SeqCtx<TC>>> C((size_t)B);
+    std::vector<SeqOracle<TC>> ho((size_t)B);
+    std::vector<CwReq<TC>> hr((size_t)B);
+    DBuf<int64_t> ptr((size_t)B * (size_t)(n + 2));
+    WaveletHost net;                                          // (the general oracle of the rare pair outside the table: one counter for all)
+    ensure_net_counter(A, net);
+    for (int64_t b = 0; b < B; b++) {
+        C[(size_t)b].reset(new SeqCtx<TC>());
+        SeqCtx<TC> &c = *C[(size_t)b];
+        build_dev_model<TC>(models + b, c.HM, s);
+        memset(&c.O, 0, sizeof(c.O));
+        c.O.M = c.HM.d; c.O.pos = A->pos.p; c.O.row = A->row.p; c.O.n = n; c.O.m = A->m;
+        c.O.has_net = 1; c.O.net = net.d;
+        ho[(size_t)b] = c.O;
+        CwReq<TC> &R = hr[(size_t)b];
+        memset(&R, 0, sizeof(R));
+        R.M = c.HM.d; R.alpha = model_param<TC>(models + b, CP_P_ALPHA); R.w = (int32_t)wmax[b]; R.ptr = ptr.p + (size_t)b * (size_t)(n + 2);
+    }
+    DBuf<int32_t> NT((size_t)(n + 2) * (size_t)FWs), st((size_t)B);
+    DBuf<SeqOracle<TC>> odev((size_t)B);
+    DBuf<CwReq<TC>> dreq((size_t)B);
+    CP_HIP(hipMemsetAsync(st.p, 0, st.bytes(), s));
+    CP_HIP(hipMemcpyAsync(odev.p, ho.data(), sizeof(SeqOracle<TC>) * (size_t)B, hipMemcpyHostToDevice, s));
+    CP_HIP(hipMemcpyAsync(dreq.p, hr.data(), sizeof(CwReq<TC>) * (size_t)B, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(PROF_CHUNK, s, 0.0);
+        hipLaunchKernelGGL(k_window_nets, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, Wc, A->pos.p, A->next.p, NT.p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack_convex_win_batch<TC>), dim3((unsigned)B), dim3(64), 0, s, dreq.p, odev.p, (int32_t)n, NT.p, (int32_t)FWs,
+                           A->pos.p, st.p);
+    }
+    CP_HIP(hipGetLastError());
+    std::vector<int32_t> hst((size_t)B);
+    std::vector<int64_t> h((size_t)n + 2), sp((size_t)n + 1);
+    CP_HIP(hipMemcpyAsync(hst.data(), st.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    CP_HIP(hipStreamSynchronize(s));
+    prof_collect();
+    for (int64_t b = 0; b < B; b++) {
+        if (hst[(size_t)b] != CP_OK) { set_error("ConvexTotalChunker: a single column exceeds w_max"); return hst[(size_t)b]; }
+        CP_HIP(hipMemcpy(h.data(), ptr.p + (size_t)b * (size_t)(n + 2), sizeof(int64_t) * (size_t)(n + 2), hipMemcpyDeviceToHost));
+        for (int64_t jp = 1; jp <= n + 1; jp++) sp[(size_t)jp - 1] = h[(size_t)jp];
+        const int64_t K = unravel_chunks_host(sp, n);
+        CP_REQUIRE(K + 1 <= ld, CP_EINVAL, "ld is smaller than a request's number of chunks + 1 (n + 1 always suffices)");
+        for (int64_t k = 0; k <= K; k++) spl_out[(size_t)b * (size_t)ld + (size_t)k] = sp[(size_t)k];
+        K_out[b] = K;
+    }
+    return CP_OK;
+}
+
 template <typename TC>
 int32_t run_partition_convex(cp_csr_s *A, int64_t K, const cp_model_t *mdl, const cp_rowpart_t *Pi, const cp_model_t *w, int64_t wi,
                              double wf, int64_t *spl_out)
@@ -1173,6 +1291,23 @@ int32_t cp_pack_convex(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *
         CP_HIP(hipSetDevice(A->device));
         if (model->dtype == CP_I64) return run_pack_convex<int64_t>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
         return run_pack_convex<double>(A, model, Pi, weight, wmax_i64, wmax_f64, spl_out, K_out);
+    } CP_CATCH_ALL
+}
+
+int32_t cp_pack_convex_batch(cp_csr_t A, int64_t B, const cp_model_t *models, const int64_t *wmax, int64_t ld, int64_t *spl_out, int64_t *K_out)
+{
+    try {
+        CP_REQUIRE(A && models && wmax && spl_out && K_out && B >= 1 && B <= 65535 && ld >= 2, CP_EINVAL, "bad argument");
+        CP_REQUIRE(A->n >= 1 && (double)(A->n + 2) * (double)(2 * CW_MAXW + 3) < 2e9, CP_EUNSUPPORTED, "pattern too small / too large for the window table");
+        for (int64_t b = 0; b < B; b++) {
+            CP_REQUIRE(seq_model_ok(models + b) && models[b].dtype == models[0].dtype, CP_EINVAL, "bad model in the batch (one element type per batch)");
+            CP_REQUIRE((models[b].kind == CP_MODEL_COLBLOCK || models[b].kind == CP_MODEL_CONNECTIVITY || models[b].kind == CP_MODEL_WORK) && !models[b].alpha_k,
+                       CP_EUNSUPPORTED, "a batch takes ColumnBlock / Connectivity / Work models without per-part alpha");
+            CP_REQUIRE(wmax[b] >= 1 && wmax[b] <= CW_MAXW, CP_EUNSUPPORTED, "a batch takes width limits 1 .. 15 (the LDS-resident window kernel)");
+        }
+        CP_HIP(hipSetDevice(A->device));
+        if (models[0].dtype == CP_I64) return run_pack_convex_batch<int64_t>(A, B, models, wmax, ld, spl_out, K_out);
+        return run_pack_convex_batch<double>(A, B, models, wmax, ld, spl_out, K_out);
     } CP_CATCH_ALL
 }
 

@@ -42,6 +42,34 @@ def width_windows(n, K, w):
     return lo, hi
 
 
+def width_of_weight(weight, w_max, n):
+    """The number of columns a WIDTH weight allows: VertexCount() -> w_max; AffineWorkModel(alpha, c, 0), c > 0 -> the largest nv with
+    alpha + nv * c <= w_max in the weight's own arithmetic (the C library's width_of_weight, csrc/capi.hip; the reference's tests
+    constrain with AffineWorkModel(0, 1, 0), test/test_Partitioners.jl:178-183).  None: not a function of the width."""
+    if isinstance(weight, M.VertexCount):
+        return int(w_max)
+    if not isinstance(weight, M.AffineWorkModel) or getattr(weight, "alpha_k", None) is not None:
+        return None
+    if weight.beta_pin != 0 or not weight.beta_vertex > 0:
+        return None
+    if weight.dtype == M.CP_I64:
+        fits = lambda nv: int(weight.alpha) + nv * int(weight.beta_vertex) <= int(w_max)
+    else:
+        fits = lambda nv: (np.float64(weight.alpha) + np.float64(nv) * np.float64(weight.beta_vertex)) + np.float64(0) * np.float64(weight.beta_pin) <= np.float64(w_max)
+    if not fits(0):
+        return -1
+    lo, hi = 0, n + 1
+    if fits(hi):
+        return hi
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if fits(mid):
+            lo = mid
+        else:
+            hi = mid
+    return lo
+
+
 class TiledDP:
     """One rank's share of the DP.  Per layer k: `begin_layer(k)`, `step_layer(k)` (computes this rank's tile of layer k into
     `cur`), then the caller completes `cur` (all_gather of `slice_of(k)` from every rank), `complete_layer(k)`, `swap()`."""
@@ -51,14 +79,15 @@ class TiledDP:
         self.hip, self.handle, self.n, self.K, self.rank, self.world = hip, handle, n, K, rank, world
         self.mm = mdl.marshal(w_table=n + 1)
         self.windowed = weight is not None
-        if self.windowed and not isinstance(weight, M.VertexCount):
-            raise NotImplementedError("the tiled constrained DP takes the width weight VertexCount() only")
+        wv = width_of_weight(weight, w_max, n) if self.windowed else None
+        if self.windowed and (wv is None or wv < 1):
+            raise NotImplementedError("the tiled constrained DP takes width weights only: VertexCount() or AffineWorkModel(alpha, c, 0) with room for a column")
         self.dtype = torch.int64 if mdl.dtype == M.CP_I64 else torch.float64
         self.big = (1 << 61) if mdl.dtype == M.CP_I64 else float(1 << 60)
         self.tiles, self.tile = tile_bounds(n, world)
         self.feasible = True
         if self.windowed:
-            self.w = int(w_max)
+            self.w = int(wv)
             self.lo, self.hi = width_windows(n, K, self.w)
             self.feasible = self.hi[K] >= n + 1
             self.tile = max(1, max(-(-(self.hi[k] - self.lo[k] + 1) // world) for k in range(1, K + 1)))

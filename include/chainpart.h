@@ -123,6 +123,13 @@ int32_t cp_pack_dynamic(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_
 /* partition_stripe(A, K, [Flip]BisectCostBottleneckSplitter(f, eps))  BisectCostBottleneckSplitter.jl:6-127 */
 int32_t cp_partition_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t *model, double eps,
                                  int32_t flip, int64_t *spl_out /* K+1 */);
+/* B independent BisectCostBottleneckSplitter partitions of ONE pattern in one launch (BisectCostBottleneckSplitter.jl:6-63 per request
+ * b: K[b], models[b] (Work or Connectivity, one element type for the batch), eps[b], flip[b] (NULL: 0)): the probe chain of a single
+ * partition is sequential and fills one wave; a sweep over K / eps / model constants fills the chip and shares the counting
+ * structure.  Row b of spl_out (ld >= max K + 1 entries per row) holds the K[b] + 1 split indices of request b -- exactly what
+ * cp_partition_bisect_cost returns for it. */
+int32_t cp_partition_bisect_cost_batch(cp_csr_t csr, int64_t B, const int64_t *K, const cp_model_t *models, const double *eps,
+                                       const int32_t *flip, int64_t ld, int64_t *spl_out);
 /* the same two with the row partition the plaid cost models need: partition_stripe(A, K, method, Pi)
  * (CP_MODEL_PRIMARY / CP_MODEL_SECONDARY; Pi is ignored by every other model, Costs.jl:5-7) */
 int32_t cp_partition_bisect_cost_pi(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi, double eps,
@@ -152,6 +159,13 @@ int32_t cp_partition_lazy_bisect_cost(cp_csr_t csr, int64_t K, const cp_model_t 
 int32_t cp_pack_convex(cp_csr_t csr, const cp_model_t *model, const cp_rowpart_t *Pi,
                        const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
                        int64_t *spl_out /* n+1 */, int64_t *K_out);
+/* B independent pack_stripe(A, ConvexTotalChunker(ConstrainedCost(models[b], VertexCount(), wmax[b]))) calls on ONE pattern in one
+ * launch (ConvexTotalChunker.jl:141-168, 211-265 per request): the stack algorithm is a dependent chain that occupies one wave
+ * whatever the size of the matrix; a sweep over the cost constants / width limits occupies one wave per request, and the requests
+ * share the net counter and the window table of net counts.  Requests: ColumnBlock / Connectivity / Work models (one element type,
+ * no per-part alpha), 1 <= wmax[b] <= 15.  Row b of spl_out (ld entries per row; n + 1 always suffices) holds the K_out[b] + 1 chunk
+ * boundaries of request b -- exactly what cp_pack_convex returns for it. */
+int32_t cp_pack_convex_batch(cp_csr_t csr, int64_t B, const cp_model_t *models, const int64_t *wmax, int64_t ld, int64_t *spl_out, int64_t *K_out);
 int32_t cp_partition_convex(cp_csr_t csr, int64_t K, const cp_model_t *model, const cp_rowpart_t *Pi,
                             const cp_model_t *weight, int64_t wmax_i64, double wmax_f64,
                             int64_t *spl_out /* K+1 */);

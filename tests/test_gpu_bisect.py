@@ -51,3 +51,29 @@ def test_cost_bisection_that_cannot_terminate_is_reported(hip, orc):
                      cp.LazyBisectCostBottleneckSplitter(cp.AffineConnectivityModel(-50, 0, 0, 0), 0.01)):
             with pytest.raises(AssertionError):
                 cp.partition_stripe(A, 4, meth, backend=b)
+
+
+def test_bisect_cost_batch_equals_the_loop_and_the_oracle(hip, orc):
+    """cp_partition_bisect_cost_batch: B requests (K, model, eps, flip) on one pattern in ONE launch, one wave each, the counting
+    structure built once.  Every split vector must be the single call's -- and the oracle's (BisectCostBottleneckSplitter.jl:6-63)."""
+    from util import suitesparse_shaped
+    A = suitesparse_shaped(20000, 8, 13)
+    reqs = []
+    for K in (2, 3, 7, 16, 32, 100):
+        for eps in (0.1, 0.01, 0.001):
+            reqs.append((K, cp.BisectCostBottleneckSplitter(cp.AffineWorkModel(0, 10, 1), eps)))
+            reqs.append((K, cp.BisectCostBottleneckSplitter(cp.AffineConnectivityModel(0, 10, 1, 100), eps)))
+            reqs.append((K, cp.BisectCostBottleneckSplitter(cp.AffineConnectivityModel(3, 0, 1, 7), eps)))
+            reqs.append((K, cp.FlipBisectCostBottleneckSplitter(cp.AffineConnectivityModel(0, 10, 1, 100), eps)))
+    got = cp.partition_stripe_batch(A, reqs, backend=hip)
+    assert len(got) == len(reqs)
+    for (K, m), g in zip(reqs, got):
+        assert g == cp.partition_stripe(A, K, m, backend=hip), (K, type(m).__name__, m.eps)
+    for (K, m), g in list(zip(reqs, got))[::5]:
+        assert g == cp.partition_stripe(A, K, m, backend=orc), (K, type(m).__name__, m.eps)
+    # Float64 batch; mixed element types are refused
+    fr = [(K, cp.BisectCostBottleneckSplitter(cp.AffineConnectivityModel(0.5, 0.25, 0.0, 1.5), 0.01)) for K in (2, 5, 9)]
+    for (K, m), g in zip(fr, cp.partition_stripe_batch(A, fr, backend=hip)):
+        assert g == cp.partition_stripe(A, K, m, backend=orc)
+    with pytest.raises(NotImplementedError):
+        cp.partition_stripe_batch(A, reqs[:1] + fr[:1], backend=hip)

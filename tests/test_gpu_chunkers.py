@@ -123,3 +123,24 @@ def test_convex_chunker_on_a_non_convex_cost_at_scale(hip, orc):
     got = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=hip)
     want = cp.pack_stripe(A, cp.DynamicTotalChunker(f), backend=orc)
     assert got == want
+
+
+def test_pack_convex_batch_equals_the_loop_and_the_oracle(hip, orc):
+    """cp_pack_convex_batch: B ConvexTotalChunker requests (model constants x width limits) on one pattern in ONE launch, one wave each,
+    sharing the net counter and the window table of net counts.  Every chunk vector must be the single call's -- and the oracle's."""
+    from util import banded, suitesparse_shaped
+    for A in (banded(3000, 16, 0.5, 4), suitesparse_shaped(2500, 6, 9)):
+        meths = []
+        for w in (1, 2, 4, 8, 12, 15):
+            for a in (1, 3, 10):
+                meths.append(cp.ConvexTotalChunker(cp.ConstrainedCost(cp.ColumnBlockComponentCostModel(a, lambda x, a=a: a + x), cp.VertexCount(), w)))
+            meths.append(cp.ConvexTotalChunker(cp.ConstrainedCost(cp.AffineConnectivityModel(2, 3, 1, 5), cp.VertexCount(), w)))
+            meths.append(cp.ConvexTotalChunker(cp.ConstrainedCost(cp.AffineWorkModel(7, 1, 2), cp.VertexCount(), w)))
+        got = cp.pack_stripe_batch(A, meths, backend=hip)
+        assert len(got) == len(meths)
+        for m, g in zip(meths, got):
+            one = cp.pack_stripe(A, m, backend=hip)
+            assert g == one, (A, type(M_ := cp.models.split_constraint(m.f)[0]).__name__, cp.models.split_constraint(m.f)[2])
+            assert int(np.diff(g.spl).max()) <= cp.models.split_constraint(m.f)[2]
+        for m, g in list(zip(meths, got))[::4]:
+            assert g == cp.pack_stripe(A, m, backend=orc)

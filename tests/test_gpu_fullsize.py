@@ -43,6 +43,26 @@ def test_config3_shape_total_dp_reaches_closed_form_optimum(hip):
             rc2, opt = hip.objective(h, 1, whole, mm, None, 0)
             assert rc == 0 and rc2 == 0
             assert got == opt, (mdl.kind, K, got, opt)
+        # Float64 twin of the headline model, AffineConnectivityModel(0.0, 0.0, 0.0, 1.0) (test/test_Partitioners.jl:176): the same split
+        # vector as the Int64 model and a floating-point total within 1e-12 relative of the exact integer total (north_star's tolerance)
+        K = 6
+        si, sf = np.zeros(K + 1, dtype=np.int64), np.zeros(K + 1, dtype=np.int64)
+        mi, mf = cp.AffineConnectivityModel(0, 0, 0, 1).marshal(), cp.AffineConnectivityModel(0.0, 0.0, 0.0, 1.0).marshal()
+        assert hip.partition_dynamic(h, K, 0, 0, mi, None, None, 0, 0.0, si) == 0, hip.last_error()
+        assert hip.partition_dynamic(h, K, 0, 0, mf, None, None, 0, 0.0, sf) == 0, hip.last_error()
+        assert np.array_equal(si, sf)
+        rc, ti = hip.objective(h, K, si, mi, None, 0)
+        rc, tf = hip.objective(h, K, sf, mf, None, 0)
+        assert isinstance(tf, float) and abs(tf - float(ti)) <= 1e-12 * abs(float(ti)), (ti, tf)
+        # ... and of the width-constrained DP (a non-degenerate answer)
+        w = -(-3 * n // (2 * K))
+        wm = cp.VertexCount().marshal()
+        assert hip.partition_dynamic(h, K, 0, 0, mi, None, wm, w, float(w), si) == 0, hip.last_error()
+        assert hip.partition_dynamic(h, K, 0, 0, mf, None, wm, w, float(w), sf) == 0, hip.last_error()
+        assert np.array_equal(si, sf) and len(set(si.tolist())) > 2
+        rc, ti = hip.objective(h, K, si, mi, None, 0)
+        rc, tf = hip.objective(h, K, sf, mf, None, 0)
+        assert abs(tf - float(ti)) <= 1e-12 * abs(float(ti)), (ti, tf)
         # K = 1 is the identity partition
         spl = np.zeros(2, dtype=np.int64)
         assert hip.partition_dynamic(h, 1, 0, 0, cp.AffineConnectivityModel(0, 0, 0, 1).marshal(), None, None, 0, 0.0, spl) == 0

@@ -152,3 +152,36 @@ def test_round_a_caches_change_no_table_cell_at_3e5(hip):
                 hip.set_option("dbg", 0)
             assert rc1 == 0 and np.array_equal(lo0, lo1) and np.array_equal(hi0, hi1)
             assert np.array_equal(p0, p1) and np.array_equal(c0, c1), (K, w, dbg)
+
+
+def test_width_weights_take_the_windowed_path(hip, orc):
+    """The reference's own tests constrain with AffineWorkModel(0, 1, 0) -- the width under another name
+    (test/test_Partitioners.jl:178-183, 256-261).  Any weight alpha + c * width (c > 0, no pin term) bounds the parts by a number of
+    columns: it must give the oracle's (literal, Theta(sum window^2)) answer AND run on the windowed O(K n log^2 n) path -- the leaf
+    pass only exists there (the one-wave literal kernel never launches it)."""
+    net = MODELS[1]
+    weights = [(cp.AffineWorkModel(0, 1, 0), lambda w: w), (cp.AffineWorkModel(0, 3, 0), lambda w: 3 * w + 2), (cp.AffineWorkModel(5, 2, 0), lambda w: 2 * w + 5),
+               (cp.AffineWorkModel(0.0, 0.5, 0.0), lambda w: 0.5 * w + 0.25), (cp.AffineWorkModel(0.25, 0.1, 0.0), lambda w: 0.1 * w + 0.25)]
+    nondeg = 0
+    for A in [suitesparse_shaped(3000, 8, 1), banded(2500, 6, 0.5, 3), golden_matrices()["HB/can_292"]]:
+        n = A.n
+        for K in (3, 8):
+            for w in sorted({-(-3 * n // (2 * K)), n // 2, 100}):
+                for wm, wmax_of in weights:
+                    f = cp.ConstrainedCost(net, wm, wmax_of(w))
+                    for meth in (cp.DynamicTotalSplitter, cp.DynamicTotalChunker):
+                        hip.prof_reset(); hip.prof_enable(True)
+                        try:
+                            got = cp.partition_stripe(A, K, meth(f), backend=hip)
+                        finally:
+                            hip.prof_enable(False)
+                        want = cp.partition_stripe(A, K, meth(f), backend=orc)
+                        assert got == want, (A, K, w, wm.beta_vertex, meth.__name__)
+                        if w >= 64 and got.spl[1] != 1:          # (feasible, and the window spans a leaf group)
+                            assert hip.prof_get().get("dp_leaf", {"launches": 0})["launches"] > 0, "not on the windowed path"
+                        nondeg += int(len(set(want.spl.tolist())) > 2)
+    assert nondeg > 40
+    # a weight with a pin term is NOT a width weight: still the oracle's answer (one-wave literal kernel)
+    A = suitesparse_shaped(400, 5, 2)
+    f = cp.ConstrainedCost(net, cp.AffineWorkModel(0, 1, 1), 700)
+    assert cp.partition_stripe(A, 4, cp.DynamicTotalSplitter(f), backend=hip) == cp.partition_stripe(A, 4, cp.DynamicTotalSplitter(f), backend=orc)

@@ -35,7 +35,15 @@ def cases():
                 (f"BisectCost(net,0.01),K={K}", lambda A, b, K=K: cp.partition_stripe(A, K, cp.BisectCostBottleneckSplitter(net, 0.01), backend=b)),
                 (f"ConvexTotalSplitter(lambda-1),K={K}", lambda A, b, K=K: cp.partition_stripe(A, K, cp.ConvexTotalSplitter(lam), backend=b)),
                 (f"DynamicTotalSplitter(Constrained(net,work-width,12)),K={K}",
-                 lambda A, b, K=K: cp.partition_stripe(A, K, cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.AffineWorkModel(0, 1, 0), -(-A.n // K) + 4)), backend=b))]
+                 lambda A, b, K=K: cp.partition_stripe(A, K, cp.DynamicTotalSplitter(cp.ConstrainedCost(net, cp.AffineWorkModel(0, 1, 0), -(-A.n // K) + 4)), backend=b)),
+                # the reference's own script: DynamicTotalSplitter(ConstrainedCost(lambda-1, VertexCount(), ceil(1.5 n / K)))
+                # (bin/test_table_constrained_splits.jl:28) -- on the GPU the windowed O(K n log^2 n) path -- and the hyperedge / chunker-order twins
+                (f"DynamicTotalSplitter(Constrained(lambda-1,VertexCount,1.5n/K)),K={K}",
+                 lambda A, b, K=K: cp.partition_stripe(A, K, cp.DynamicTotalSplitter(cp.ConstrainedCost(lam, cp.VertexCount(), -(-3 * A.n // (2 * K)))), backend=b)),
+                (f"DynamicTotalSplitter(Constrained(hyperedge,VertexCount,1.5n/K)),K={K}",
+                 lambda A, b, K=K: cp.partition_stripe(A, K, cp.DynamicTotalSplitter(cp.ConstrainedCost(hyp, cp.VertexCount(), -(-3 * A.n // (2 * K)))), backend=b)),
+                (f"DynamicTotalChunker(Constrained(net,VertexCount,1.5n/K)),K={K}",
+                 lambda A, b, K=K: cp.partition_stripe(A, K, cp.DynamicTotalChunker(cp.ConstrainedCost(net, cp.VertexCount(), -(-3 * A.n // (2 * K)))), backend=b))]
     out += [("DynamicTotalChunker(net,8)", lambda A, b: cp.pack_stripe(A, cp.DynamicTotalChunker(cp.ConstrainedCost(net, cp.VertexCount(), 8)), backend=b)),
             ("DynamicTotalChunker(col_block,8)", lambda A, b: cp.pack_stripe(A, cp.DynamicTotalChunker(cp.ConstrainedCost(colb, cp.VertexCount(), 8)), backend=b)),
             ("ConvexTotalChunker(col_block,8)", lambda A, b: cp.pack_stripe(A, cp.ConvexTotalChunker(cp.ConstrainedCost(colb, cp.VertexCount(), 8)), backend=b)),
@@ -47,6 +55,7 @@ def matrices():
     m = dict(golden_matrices())
     m["synthetic/suitesparse_shaped(300,5,seed=1)"] = suitesparse_shaped(300, 5, 1)
     m["synthetic/banded(200,4,0.5,seed=2)"] = banded(200, 4, 0.5, 2)
+    m["synthetic/suitesparse_shaped(1500,6,seed=3)"] = suitesparse_shaped(1500, 6, 3)      # (wide enough for windows that span the 64-row leaf groups)
     return m
 
 
