@@ -236,8 +236,11 @@ int32_t cp_get_stat(const char *name, int64_t *out);
  * "ra_cache" (round A from counts cached per partition), "nospec" 1 (one host sync per round instead of sizing a layer from the
  * previous one), "rpass_ch"/"rpass_small_tau"/"rpass_cap" (right-part passes: columns per wave, last
  * lane-per-row round, lane-private share of a row in per cent of the mean), "setup_bs" (lanes per block of the task setup), "force_max" (a round whose flattened
- * stage served at most this many tasks gives them tiles of their own from the next layer on), "bn_chunk"
- * (rows per walk of the bottleneck DP), "prof_only" slot (events on one profile slot only), "dbg"
+ * stage served at most this many tasks gives them tiles of their own from the next layer on), "leaf" (1: the rounds tau < 6 of a
+ * layer are one leaf pass, csrc/dp_leaf.inc; 0: divide-and-conquer rounds down to tau = 0), "block_tables" (1: the leaf pass also
+ * stores every per-block winner, needed by cp_dp_block_tables), "poison" (1: test mode of cp_get_stat above), "fixed_point" (1: layers
+ * after one that reproduced its input row are copied), "bn_wave" (bottleneck DP walk: 0 lane per chunk of "bn_chunk" rows, 1 wave
+ * per run of "bn_run" rows in lockstep, 2 = default: searched crossings for Int64 costs), "bn_slack" (columns of the start bracket), "prof_only" slot (events on one profile slot only), "dbg"
  * (diagnostic bit mask).  Unknown names return CP_EINVAL. */
 int32_t cp_set_option(const char *name, int64_t value);
 /* built-in per-kernel HIP-event timing of the named hot kernels on the launch stream */

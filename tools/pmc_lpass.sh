@@ -1,17 +1,20 @@
 #!/bin/bash
 # Collect HBM traffic counters for the dominant kernel (k_lpass_own) with rocprofv3, as MI355X_MICROARCH.md
 # "HBM" prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), kernel-trace only.
-# Run on the GPU box:  bash tools/pmc_lpass.sh   -> gpurun_out/pmc_r02/{fetch,write}/...
+# Run on the GPU box:  bash tools/pmc_lpass.sh [tag] [commit]   -> gpurun_out/pmc_<tag>/summary.json (tag defaults to r03)
 set -e
+TAG=${1:-r03}; COMMIT=${2:-unknown}
+export TAG COMMIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/pmc_r02
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_r02/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --parts 4 > gpurun_out/pmc_r02/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_r02/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --parts 4 > gpurun_out/pmc_r02/write.log 2>&1
+mkdir -p gpurun_out/pmc_$TAG
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$TAG/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --parts 4 > gpurun_out/pmc_$TAG/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_$TAG/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --parts 4 > gpurun_out/pmc_$TAG/write.log 2>&1
 python3 - <<'PY'
-import csv, glob, json
+import csv, glob, json, os
+TAG = os.environ['TAG']
 out = {}
 for name in ("fetch", "write"):
-    f = glob.glob(f"gpurun_out/pmc_r02/{name}/*/*_counter_collection.csv")
+    f = glob.glob(f"gpurun_out/pmc_{TAG}/{name}/*/*_counter_collection.csv")
     rows = list(csv.DictReader(open(f[0])))
     cname = "FETCH_SIZE" if name == "fetch" else "WRITE_SIZE"
     # the plain streaming kernel k_lpass_own<TC, HYP, GAP = false> (the gap-pass variant is a different kernel and profile slot)
@@ -20,7 +23,7 @@ for name in ("fetch", "write"):
     vals = [float(r["Counter_Value"]) for r in rows if plain(r["Kernel_Name"]) and r["Counter_Name"] == cname]
     out[cname] = {"launches": len(vals), "sum": sum(vals), "mean_per_launch": sum(vals) / max(len(vals), 1)}
 # bench line of the fetch run gives the algorithmic bytes per launch at the same configuration
-for line in open("gpurun_out/pmc_r02/fetch.log"):
+for line in open(f"gpurun_out/pmc_{TAG}/fetch.log"):
     if line.startswith("{"):
         d = json.loads(line)
         out["alg_bytes_per_launch"] = d["roofline"]["alg_bytes_per_launch"]
@@ -34,6 +37,8 @@ out["note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in 
                "link-array stream is 16 B/lane, the remaining reads (colptr, previous-layer cost, tile records) are 4-16 B/lane and uncalibrated; "
                "the stores are the tile records only (16 B + 4 B per 256-step tile -- round 1 also wrote 96 B of private scratch per lane here): traffic_bytes_per_launch_corrected = (2*FETCH_SIZE + WRITE_SIZE) * 1024 is an upper "
                "estimate, traffic_bytes_per_launch_raw = (FETCH_SIZE + WRITE_SIZE) * 1024 a lower one.")
-json.dump(out, open("gpurun_out/pmc_r02/summary.json", "w"), indent=1)
+out["measured_at"] = os.environ.get("COMMIT", "unknown")
+json.dump(out, open(f"gpurun_out/pmc_{TAG}/summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+rm -rf gpurun_out/pmc_$TAG/fetch gpurun_out/pmc_$TAG/write
