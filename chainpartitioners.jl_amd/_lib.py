@@ -21,7 +21,7 @@ SYMBOLS = [
     "cp_csr_reset_cache", "cp_count_build", "cp_count_query", "cp_count_destroy", "cp_link_array", "cp_partwise", "cp_domsum_build", "cp_rook_build", "cp_wsum_query", "cp_wsum_destroy",
     "cp_oracle_eval", "cp_oracle_step", "cp_bound_stripe", "cp_objective", "cp_partition_dynamic", "cp_pack_dynamic",
     "cp_partition_bisect_cost", "cp_partition_bisect_cost_batch", "cp_pack_convex", "cp_pack_convex_batch", "cp_partition_convex", "cp_partition_equi", "cp_pack_equi",
-    "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_set_stream", "cp_reset_stream", "cp_get_stat", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
+    "cp_dynamic_tables", "cp_dynamic_tables_constrained", "cp_dynamic_tables_constrained_combine", "cp_set_stream", "cp_reset_stream", "cp_get_stat", "cp_set_option", "cp_prof_enable", "cp_prof_reset", "cp_prof_get",
     "cp_dp_begin", "cp_dp_layer", "cp_dp_ptr_at", "cp_dp_destroy", "cp_dp_ptr_row", "cp_dp_block_tables", "cp_dp_set_window", "cp_dp_set_rows",
     "cp_partition_bisect_index", "cp_partition_lazy_bisect_cost", "cp_pack_concave", "cp_partition_concave",
     "cp_adjoint", "cp_csr_download", "cp_bound_stripe_pi", "cp_partition_bisect_cost_pi", "cp_partition_bisect_index_pi",
@@ -249,14 +249,15 @@ class HipBackend:
                                         _p(cst) if mm.struct.dtype == M.CP_F64 else None)
         return rc, ptr.T, cst.T
 
-    def dynamic_tables_constrained(self, A, K, mm, wmax):
-        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of DynamicTotalSplitter(ConstrainedCost(f, VertexCount(), wmax))"""
+    def dynamic_tables_constrained(self, A, K, mm, wmax, combine=0):
+        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of Dynamic{Total,Bottleneck}Splitter(ConstrainedCost(f, VertexCount(), wmax))
+        (combine 0 = total, 1 = bottleneck)"""
         ptr = np.zeros((K, A.n + 1), dtype=np.int64)
         cst = np.zeros((K, A.n + 1), dtype=np.int64 if mm.struct.dtype == M.CP_I64 else np.float64)
         lo = np.zeros(K, dtype=np.int64); hi = np.zeros(K, dtype=np.int64)
-        rc = self.lib.cp_dynamic_tables_constrained(self._h(A), _i64(K), mm.ptr, _i64(wmax), _p(lo), _p(hi), _p(ptr),
-                                                    _p(cst) if mm.struct.dtype == M.CP_I64 else None,
-                                                    _p(cst) if mm.struct.dtype == M.CP_F64 else None)
+        rc = self.lib.cp_dynamic_tables_constrained_combine(self._h(A), _i64(K), C.c_int32(combine), mm.ptr, _i64(wmax), _p(lo), _p(hi), _p(ptr),
+                                                            _p(cst) if mm.struct.dtype == M.CP_I64 else None,
+                                                            _p(cst) if mm.struct.dtype == M.CP_F64 else None)
         return rc, lo, hi, ptr.T, cst.T
 
     # ---- counting structures

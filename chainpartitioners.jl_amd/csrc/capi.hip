@@ -278,9 +278,14 @@ static void width_windows(int64_t n, int64_t K, int64_t w, std::vector<int64_t> 
     for (int64_t k = 1; k <= K; k++) { hi[(size_t)k] = (w >= n + 1 - j) ? n + 1 : j + w; j = hi[(size_t)k]; }
 }
 
+// combine = CP_COMBINE_MAX (DynamicBottleneck*(ConstrainedCost(...))): the same windows; the valley search of dp_bottleneck.hip takes
+// the layer's candidate limits directly (no masked row: the crossing is searched inside [max(lo[k-1], j' - w), min(j', hi[k-1])],
+// where the previous layer's costs are finite and still grow with the prefix -- dropping the last column of a feasible prefix
+// keeps every width <= w).
 template <typename TC>
 static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const cp_model_t *mdl, int64_t wmax,
-                                    int64_t *spl_out, int64_t *ptr_tab, TC *cst_tab, int64_t *win_lo, int64_t *win_hi)
+                                    int64_t *spl_out, int64_t *ptr_tab, TC *cst_tab, int64_t *win_lo, int64_t *win_hi,
+                                    int32_t combine = CP_COMBINE_SUM)
 {
     hipStream_t s = A->stream;
     const int64_t n = A->n;
@@ -327,10 +332,14 @@ static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const
         }
     };
     dump_layer(1);
-    void *work = dp_total_work_get<TC>(A);
+    void *work = combine == CP_COMBINE_SUM ? dp_total_work_get<TC>(A) : nullptr;
     for (int64_t k = 2; k <= K; k++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mask_row<TC>), dim3(g1), dim3(256), 0, s, (int64_t)n1, lo[(size_t)k - 1] - 1, hi[(size_t)k - 1] - 1, cst.p, Wm.p);
-        dp_total_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, work, lo[(size_t)k] - 1, hi[(size_t)k] - 1, w);
+        if (combine == CP_COMBINE_SUM)
+            dp_total_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, work, lo[(size_t)k] - 1, hi[(size_t)k] - 1, w);
+        else
+            dp_bottleneck_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, lo[(size_t)k] - 1, hi[(size_t)k] - 1,
+                                    w, lo[(size_t)k - 1] - 1, hi[(size_t)k - 1] - 1);
         dump_layer(k);
     }
     // unravel_splits (DynamicSplitter.jl:89-99); every visited cell lies in its layer's window
@@ -351,6 +360,11 @@ static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const
 // the scalable path takes: total cost, a model of the inverse-Monge class, the width weight, w_max >= 1
 static bool windowed_ok(cp_csr_s *A, int64_t K, int32_t combine, const cp_model_t *model, const cp_model_t *weight, int64_t wmax)
 {
+    // bottleneck: the searched-crossings walk carries the candidate limits (Int64 costs; dp_bottleneck.hip)
+    if (combine == CP_COMBINE_MAX)
+        return weight && weight->kind == CP_MODEL_VERTEX_COUNT && wmax >= 1 && !g_opt_force_brute && model->dtype == CP_I64 &&
+               g_opt_bn_wave >= 2 && (model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT) &&
+               fast_bottleneck_ok(model, A->n, A->N, K);
     return combine == CP_COMBINE_SUM && weight && weight->kind == CP_MODEL_VERTEX_COUNT && wmax >= 1 && !g_opt_force_brute &&
            (model->kind == CP_MODEL_WORK || model->kind == CP_MODEL_CONNECTIVITY || model->kind == CP_MODEL_HYPEREDGE_CUT) &&
            fast_total_ok(model, A->n, A->N, K);
@@ -726,8 +740,8 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
             const int64_t wv = width_of_weight(weight, A->n, wmax_i64, wmax_f64);
             cp_model_t vc{}; vc.kind = CP_MODEL_VERTEX_COUNT; vc.dtype = CP_I64;
             if (wv >= 1 && windowed_ok(A, K, combine, model, &vc, wv)) {      // O(K n log^2 n): the windowed geometry of dp_total.hip
-                if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr);
-                return run_dynamic_windowed<double>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr);
+                if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr, combine);
+                return run_dynamic_windowed<double>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr, combine);
             }
             if (model->dtype == CP_I64) return run_dyn_constrained<int64_t>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
             return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
@@ -757,18 +771,25 @@ int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model
     });
 }
 
-int32_t cp_dynamic_tables_constrained(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t wmax, int64_t *win_lo, int64_t *win_hi,
-                                      int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+int32_t cp_dynamic_tables_constrained_combine(cp_csr_t A, int64_t K, int32_t combine, const cp_model_t *model, int64_t wmax,
+                                              int64_t *win_lo, int64_t *win_hi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
 {
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && ptr_out && win_lo && win_hi && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
+        CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
         cp_model_t vc{}; vc.kind = CP_MODEL_VERTEX_COUNT; vc.dtype = CP_I64;
-        CP_REQUIRE(windowed_ok(A, K, CP_COMBINE_SUM, model, &vc, wmax), CP_EUNSUPPORTED, "outside the windowed O(n log^2 n) path");
+        CP_REQUIRE(windowed_ok(A, K, combine, model, &vc, wmax), CP_EUNSUPPORTED, "outside the windowed scalable path");
         CP_HIP(hipSetDevice(A->device));
         std::vector<int64_t> spl((size_t)K + 1);
-        if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_i64, win_lo, win_hi);
-        return run_dynamic_windowed<double>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_f64, win_lo, win_hi);
+        if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_i64, win_lo, win_hi, combine);
+        return run_dynamic_windowed<double>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_f64, win_lo, win_hi, combine);
     });
+}
+
+int32_t cp_dynamic_tables_constrained(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t wmax, int64_t *win_lo, int64_t *win_hi,
+                                      int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+{
+    return cp_dynamic_tables_constrained_combine(A, K, CP_COMBINE_SUM, model, wmax, win_lo, win_hi, ptr_out, cst_i64, cst_f64);
 }
 
 int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint, int64_t nq,

@@ -45,6 +45,9 @@ struct BnCtx {
     DevModel<TC> M; TC alpha;
     int64_t n; int32_t hyp;
     int64_t N, NF;                       // lengths of the link arrays (next / prev) and of the row buckets (flast / lfirst)
+    // candidate limits of a width-constrained layer (DynamicSplitter.jl:233-246; 0-based): row r takes max(p_lo0, r - wwin) <= p <=
+    // min(r, p_hi0); unconstrained: wwin = 0 (no lower cut), p_lo0 = 0, p_hi0 = n
+    int64_t wwin, p_lo0, p_hi0;
     const int64_t *pos, *lpos;
     const int32_t *pos32, *prev, *next, *fpos32, *flast, *lpos32, *lfirst;
     WaveletDev net, self;
@@ -104,6 +107,14 @@ __global__ void __launch_bounds__(1024) k_bn_run3(int64_t n1, int64_t nblk, int3
     if (p < n1 && runend[p] == INT32_MAX) runend[p] = blockIdx.x + 1 < nblk ? blk_first_end[blockIdx.x + 1] : (int32_t)(n1 - 1);
 }
 
+template <typename TC> __device__ __forceinline__ int64_t bn_plo(const BnCtx<TC> &C, int64_t r)
+{
+    int64_t lo = C.p_lo0;
+    if (C.wwin > 0 && r - C.wwin > lo) lo = r - C.wwin;
+    return lo;
+}
+template <typename TC> __device__ __forceinline__ int64_t bn_phi(const BnCtx<TC> &C, int64_t r) { return r < C.p_hi0 ? r : C.p_hi0; }
+
 // counts of the part [p, r) by random access
 template <typename TC>
 __device__ __forceinline__ void bn_counts(const BnCtx<TC> &C, int64_t p, int64_t r, int64_t &nn, int64_t &nl)
@@ -140,37 +151,42 @@ __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
     if (t >= nchunk || (coarse && t % coarse == 0)) return;
     const int64_t r = rlo + t * CH;
-    int64_t lo = 0, hi = r + 1;                             // the answer lies in [lo, hi]; pred is true at hi (r + 1: "no crossing")
+    const int64_t lo0 = bn_plo(C, r), phi = bn_phi(C, r);   // the row's candidates (the whole range [0, r] without a window)
+    int64_t lo = lo0, hi = phi + 1;                         // the answer lies in [lo, hi]; pred counts as true at hi (phi + 1: "no crossing")
+    if (lo > hi) lo = hi;
     if (coarse) {
         const int64_t tl = t - t % coarse, tr = tl + coarse;
-        lo = c0[tl];                                        // c(r) >= c(left coarse row)
+        if ((int64_t)c0[tl] > lo) lo = c0[tl];              // c(r) >= c(left coarse row)
         if (tr < nchunk && (int64_t)c0[tr] < hi) hi = c0[tr];      // c(r) <= c(right coarse row)
         if (lo > hi) lo = hi;
     } else if (hint) {
         int64_t g = hint[t];
         if (hint2) g += g - (int64_t)hint2[t];                // (the crossing of the layer before as well: continue its move)
-        if (g < 0) g = 0;
-        if (g > r) g = r;
+        if (g < lo0) g = lo0;
+        if (g > phi) g = phi;
         const int64_t d0 = slack > 0 ? slack : 1;          // first gallop step
-        if (bn_pred(C, g, r)) {                             // the crossing is at or left of g: gallop left
+        if (g >= lo0 && bn_pred(C, g, r)) {                 // the crossing is at or left of g: gallop left
             hi = g;
             int64_t d = d0;
-            while (hi - d >= 0 && bn_pred(C, hi - d, r)) { hi -= d; d <<= 1; }
-            lo = hi - d >= 0 ? hi - d + 1 : 0;
-        } else {                                            // right of g
+            while (hi - d >= lo0 && bn_pred(C, hi - d, r)) { hi -= d; d <<= 1; }
+            lo = hi - d >= lo0 ? hi - d + 1 : lo0;
+        } else if (g >= lo0) {                              // right of g
             int64_t cur = g, d = d0;
-            while (cur + d <= r && !bn_pred(C, cur + d, r)) { cur += d; d <<= 1; }
+            while (cur + d <= phi && !bn_pred(C, cur + d, r)) { cur += d; d <<= 1; }
             lo = cur + 1;
-            if (cur + d <= r) hi = cur + d;
+            if (cur + d <= phi) hi = cur + d;
         }
     }
     // slack >= 0: the bracket [lo, hi] of the crossing is narrowed to `slack` columns only -- lo, a column at or left of the
     // crossing, is all the wave walks need
     const int64_t tol = slack >= 0 ? slack : 0;
     while (hi - lo > tol) {
-        const int64_t mid = (lo + hi) >> 1;                 // mid <= r
+        const int64_t mid = (lo + hi) >> 1;                 // mid <= phi
         if (bn_pred(C, mid, r)) hi = mid; else lo = mid + 1;
     }
+    // the wave walks take a column at or left of the crossing WITH the counts of its part: "no crossing" (lo == phi + 1) becomes the
+    // last candidate itself (the lane-per-chunk walk keeps the exact convention, slack < 0)
+    if (slack >= 0 && lo > phi) lo = phi;
     int64_t nn = 0, nl = 0;
     if (lo <= r) bn_counts(C, lo, r, nn, nl);
     c0[t] = (int32_t)lo; nn0[t] = (int32_t)nn; nl0[t] = (int32_t)nl;
@@ -510,8 +526,9 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
             }
         }
         const TC rowpart = cadd(cadd(C.alpha, cmulc((int64_t)r, kV)), cmulc((int64_t)posr, kP));
+        const int32_t plo_r = (int32_t)bn_plo(C, (int64_t)r), phi_r = (int32_t)bn_phi(C, (int64_t)r);      // this row's candidates [plo_r, phi_r]
         // ---- windows of 64 columns from cs - 1 on
-        int32_t c = cs;
+        int32_t c = cs, c_carry = cs;
         bool open = valid, have_fm = false, have_prev = false;
         TC fm = (TC)0, fprev = (TC)0;
         int jb = cs >= 1 ? 1 : 0;                                        // lane of the column the counts nn / nl refer to
@@ -617,11 +634,12 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
             // T(r): the right-hand side of the regrouped test
             const int32_t Pnb = __shfl(Pn, jb), Plb = HYP ? __shfl(Pl, jb) : 0;
             const TC T = cadd(rowpart, cadd(cmulc((int64_t)(nn + Pnb + snb), kN), cmulc((int64_t)(nl + Plb + slb), kL)));
-            int jmax = r - xw;                                           // largest lane whose column is <= r
+            int jmax = phi_r - xw;                                       // largest lane whose column is a candidate of the row
             if (jmax > 63) jmax = 63;
-            // lower bound over [0, jmax + 1): the first lane with G(j) + k_N S(j, r) + k_L S_L(j, r) >= T
-            int lo = 0, hi = jmax + 1;
-            if (hi < 0) hi = 0;
+            const int jmin = plo_r > xw ? plo_r - xw : 0;                // ... and the smallest (width-constrained layers)
+            // lower bound over [jmin, jmax + 1): the first lane with G(j) + k_N S(j, r) + k_L S_L(j, r) >= T
+            int lo = jmin, hi = jmax + 1;
+            if (hi < lo) hi = lo;
             const bool anyspec = ns > 0 || ns2 > 0;
 #pragma unroll
             for (int it = 0; it < 7; it++) {
@@ -636,22 +654,24 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
             // (every shuffle is done by ALL lanes, outside the divergent bookkeeping below: a lane that reads a register of an
             //  inactive lane through ds_bpermute gets zero)
             const int jp = js >= 1 ? js - 1 : 0;
-            int32_t snp = 0, slp = 0, sns = 0, sls = 0, sn63 = 0, sl63 = 0, sn64 = 0, sl64 = 0;
-            if (anyspec) { spec_counts(jp, snp, slp); spec_counts(js, sns, sls); spec_counts(63, sn63, sl63); spec_counts(64, sn64, sl64); }
+            const int jm = jmax >= 0 ? (jmax & 63) : 0;
+            int32_t snp = 0, slp = 0, sns = 0, sls = 0, sn63 = 0, sl63 = 0, sn64 = 0, sl64 = 0, snm = 0, slm = 0;
+            if (anyspec) { spec_counts(jp, snp, slp); spec_counts(js, sns, sls); spec_counts(63, sn63, sl63); spec_counts(64, sn64, sl64); spec_counts(jm, snm, slm); }
             const TC gp = shfl64_bn(G, jp & 63), wp = shfl64_bn(Wj, jp & 63);
             const int32_t Pns = __shfl(Pn, js & 63), Pls = HYP ? __shfl(Pl, js & 63) : 0;
+            const int32_t Pnm = __shfl(Pn, jm), Plm = HYP ? __shfl(Pl, jm) : 0;
             const TC g63 = rdl64_bn(G, 63), w63 = rdl64_bn(Wj, 63);
             if (open) {
                 const bool found = js <= jmax;
                 const bool none = !found && jmax < 63;                   // the row ends inside the window: c = r + 1
                 if (found || none) {
-                    c = found ? xw + js : r + 1;
-                    // f(c - 1, r): the cost at lane js - 1 (the previous window's last lane when js == 0)
-                    if (js >= 1) { fm = csub(csub(T, csub(gp, wp)), cadd(cmulc((int64_t)snp, kN), cmulc((int64_t)slp, kL))); have_fm = true; }
-                    else { fm = fprev; have_fm = have_prev; }
-                    // counts of the part [c, r) for the next anchor
-                    if (found) { nn = nn - (Pns - Pnb) - (sns - snb); nl = nl - (Pls - Plb) - (sls - slb); }
-                    else { nn = 0; nl = 0; }
+                    c = found ? xw + js : phi_r + 1;
+                    // f(c - 1, r): the cost at lane js - 1 (the previous window's last lane when js == 0) -- if c - 1 is a candidate
+                    if (js >= 1) { fm = csub(csub(T, csub(gp, wp)), cadd(cmulc((int64_t)snp, kN), cmulc((int64_t)slp, kL))); have_fm = js - 1 >= jmin; }
+                    else { fm = fprev; have_fm = have_prev && xw - 1 >= plo_r; }
+                    // column and counts the next sub-run starts from: the crossing, or -- none -- the row's last candidate phi
+                    if (found) { c_carry = c; nn = nn - (Pns - Pnb) - (sns - snb); nl = nl - (Pls - Plb) - (sls - slb); }
+                    else { c_carry = phi_r; nn = nn - (Pnm - Pnb) - (snm - snb); nl = nl - (Plm - Plb) - (slm - slb); }
                     open = false;
                 } else {
                     // beyond the window: the cost at its last lane, the counts at the next window's first column
@@ -667,15 +687,16 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
         // ---- values: min(f(c - 1, r), W[c]); the largest minimiser
         if (valid) {
             TC v; int32_t p;
-            const TC Wc = c <= r ? C.W[c] : (TC)0;
-            if (c <= r && (!have_fm || Wc <= fm)) { const int32_t re = runend[c]; v = Wc; p = re < r ? re : r; }
+            const TC Wc = c <= phi_r ? C.W[c] : (TC)0;
+            if (plo_r > phi_r) { v = CostTraits<TC>::typemax(); p = plo_r; }      // no candidate at all (the reference reads an out-of-window cell: typemax)
+            else if (c <= phi_r && (!have_fm || Wc <= fm)) { const int32_t re = runend[c]; v = Wc; p = re < phi_r ? re : phi_r; }
             else { v = fm; p = c - 1; }
             cst[r] = v; ptr[r] = p;
         }
         if (a == r_begin && lane == 0) hint_out[t] = c;                  // the next layer's starts gallop from this run's true first crossing
         if (alast >= r_end) break;
         a = alast;
-        cs = rdl_bn(c, 63); nn_a = rdl_bn(nn, 63); nl_a = rdl_bn(nl, 63);
+        cs = rdl_bn(c_carry, 63); nn_a = rdl_bn(nn, 63); nl_a = rdl_bn(nl, 63);
     }
 }
 
@@ -704,7 +725,7 @@ int64_t g_opt_bn_run = 253;       // ... rows per wave (1 + 63 m: m sub-runs of 
 
 template <typename TC>
 void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
-                         int64_t rlo, int64_t rhi)
+                         int64_t rlo, int64_t rhi, int64_t wwin, int64_t p_lo0, int64_t p_hi0)
 {
     hipStream_t s = A->stream;
     const int64_t n = A->n, n1 = n + 1;
@@ -718,6 +739,9 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     BnCtx<TC> C;
     C.M = M; C.alpha = alpha; C.n = n; C.hyp = hyp ? 1 : 0;
     C.N = A->N; C.NF = hyp ? A->nrows_nonempty : 0;
+    const bool limited = wwin > 0 || p_lo0 > 0 || (p_hi0 >= 0 && p_hi0 < n);
+    C.wwin = wwin > 0 ? wwin : 0; C.p_lo0 = p_lo0 > 0 ? p_lo0 : 0; C.p_hi0 = (p_hi0 >= 0 && p_hi0 < n) ? p_hi0 : n;
+    CP_REQUIRE(!limited || (g_opt_bn_wave >= 2 && CostTraits<TC>::is_int), CP_EINTERNAL, "candidate limits need the searched-crossings walk (Int64 costs)");
     C.pos = A->pos.p; C.lpos = hyp ? A->lpos.p : nullptr;
     C.pos32 = A->pos32.p; C.prev = A->prev.p; C.next = A->next.p;
     C.fpos32 = hyp ? A->fpos32.p : nullptr; C.flast = hyp ? A->flast.p : nullptr;
@@ -732,6 +756,7 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_run1<TC>), dim3((unsigned)nblk), dim3(1024), 0, s, n1, W, B->runend.p, B->blk.p);
     hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1024), 0, s, nblk, B->blk.p);
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
+    // (width-constrained layers move their row window from layer to layer: the hints are per chunk of ONE tiling, so they start afresh)
     const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
     if (!hinted) B->hint_layers = 0;
     B->hint.ensure((size_t)nchunk); B->hint2.ensure((size_t)nchunk);
@@ -780,7 +805,7 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     CP_HIP(hipGetLastError());
 }
 
-template void dp_bottleneck_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, int64_t, int64_t);
-template void dp_bottleneck_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, int64_t, int64_t);
+template void dp_bottleneck_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t);
+template void dp_bottleneck_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t);
 
 }  // namespace cpk

@@ -82,3 +82,76 @@ def test_bottleneck_at_bench_size_equals_bisect_index(hip):
         v_bi = cp.bottleneck_value(A, bi, mdl, backend=hip)
         assert v_dp == v_bi
         assert len(set(dp.spl.tolist())) > K // 2
+
+
+# ------------------------------------------------------------------ width-constrained bottleneck DP
+# DynamicBottleneck{Splitter,Chunker}(ConstrainedCost(f, VertexCount(), w_max)) (DynamicSplitter.jl:206-314 with g = max): the
+# searched-crossings walk with per-row candidate limits.  Int64 models take it; Float64 falls to the literal one-wave kernel.
+CMODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(0, 10, 1, 100), cp.AffineWorkModel(0, 10, 1),
+           cp.AffineHyperedgeCutModel(0, 1, 0, 3, 2), cp.AffineConnectivityModel(0, 3, 1, 3, alpha_k=[5, 1, 9, 2, 7, 3, 8, 4])]
+
+
+def _widths(n, K):
+    return sorted({max(1, -(-n // K)), max(1, -(-3 * n // (2 * K))), max(1, n // 2), max(1, n - 1), n + 3, 1, 2, 3, 5, 8, 63, 64, 65})
+
+
+@pytest.mark.parametrize("mi", range(len(CMODELS)))
+def test_constrained_bottleneck_tables_bit_exact(hip, orc, mi):
+    mdl = CMODELS[mi]
+    nondeg = 0
+    for A in mats():
+        for K in (1, 2, 5, 8):
+            for w in _widths(A.n, K):
+                mm = mdl.marshal()
+                rc2, lo2, hi2, p2, c2 = orc.dynamic_tables_constrained(A, K, 1, mm, None, cp.VertexCount().marshal(), w, float(w))
+                rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w, combine=1)
+                assert rc1 == rc2, (A, K, w, hip.last_error())
+                assert np.array_equal(lo1, lo2) and np.array_equal(hi1, hi2), (A, K, w)
+                if rc2 == 0:
+                    assert np.array_equal(p1, p2), (A, K, w, mi)
+                    assert np.array_equal(c1, c2), (A, K, w, mi)
+                for meth in (cp.DynamicBottleneckSplitter, cp.DynamicBottleneckChunker):
+                    if meth is cp.DynamicBottleneckChunker and mdl.alpha_k is not None:
+                        continue
+                    f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
+                    got = cp.partition_stripe(A, K, meth(f), backend=hip)
+                    want = cp.partition_stripe(A, K, meth(f), backend=orc)
+                    assert got == want, (A, K, w, mi, meth.__name__)
+                nondeg += int(len(set(want.spl.tolist())) > 2)
+    assert nondeg > 100
+
+
+def test_constrained_bottleneck_run_lengths_and_weights(hip, orc):
+    """sub-run lengths around the wave width, hinted / unhinted starts, and an AffineWorkModel width weight (test_Partitioners.jl:178-183)"""
+    mats_ = [suitesparse_shaped(3000, 8, 1), banded(2500, 6, 0.5, 3), suitesparse_shaped(1025, 5, 7)]
+    try:
+        for run, slack in ((253, 64), (2, 64), (63, 0), (64, 3), (65, 64), (1000, 64), (100000, 64)):
+            hip.set_option("bn_run", run); hip.set_option("bn_slack", slack)
+            for A in mats_:
+                for mdl in (CMODELS[1], CMODELS[3]):
+                    for (K, w) in [(4, -(-3 * A.n // 8)), (7, A.n // 4), (16, A.n // 8), (3, A.n // 3 + 97), (3, 700)]:
+                        mm = mdl.marshal()
+                        rc2, lo2, hi2, p2, c2 = orc.dynamic_tables_constrained(A, K, 1, mm, None, cp.VertexCount().marshal(), w, float(w))
+                        rc1, lo1, hi1, p1, c1 = hip.dynamic_tables_constrained(A, K, mm, w, combine=1)
+                        assert rc1 == rc2, hip.last_error()              # ((3, 700) is infeasible on the larger two: both say so)
+                        assert np.array_equal(p1, p2) and np.array_equal(c1, c2), (A, K, w, run, slack)
+    finally:
+        hip.set_option("bn_run", 253); hip.set_option("bn_slack", 64)
+    A = mats_[0]
+    f = cp.ConstrainedCost(CMODELS[1], cp.AffineWorkModel(0, 1, 0), 800)
+    got = cp.partition_stripe(A, 5, cp.DynamicBottleneckSplitter(f), backend=hip)
+    want = cp.partition_stripe(A, 5, cp.DynamicBottleneckSplitter(f), backend=orc)
+    assert got == want
+
+
+def test_constrained_bottleneck_against_literal_kernel_larger(hip):
+    """n = 30 000: the windowed valley search against the one-wave literal kernel (force_brute), a size the CPU oracle does not reach"""
+    A = suitesparse_shaped(30000, 8, 5)
+    f = cp.ConstrainedCost(CMODELS[1], cp.VertexCount(), 6000)
+    got = cp.partition_stripe(A, 6, cp.DynamicBottleneckSplitter(f), backend=hip)
+    hip.set_option("force_brute", 1)
+    try:
+        want = cp.partition_stripe(A, 6, cp.DynamicBottleneckSplitter(f), backend=hip)
+    finally:
+        hip.set_option("force_brute", 0)
+    assert got == want and len(set(got.spl.tolist())) == 7

@@ -35,7 +35,7 @@ def rand_matrix():
 
 
 def rand_model():
-    k = rng.integers(0, 7)
+    k = rng.integers(0, 9)
     r = lambda lo, hi: int(rng.integers(lo, hi))
     if k == 0: return cp.AffineConnectivityModel(r(-3, 4), r(-3, 4), r(-2, 3), r(0, 5))
     if k == 1: return cp.AffineConnectivityModel(0, 0, 0, 1)
@@ -43,7 +43,9 @@ def rand_model():
     if k == 3: return cp.AffineHyperedgeCutModel(r(-2, 3), r(-2, 3), r(-2, 3), r(-2, 2), r(2, 5))
     if k == 4: return cp.AffineConnectivityModel(float(r(-3, 4)), 0.0, 1.0, float(r(0, 4)))
     if k == 5: return cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1)
-    return cp.AffineConnectivityModel(0.5, 0.25, 1.0, 3.0)               # non-integral: general sweep
+    if k == 6: return cp.AffineConnectivityModel(0.5, 0.25, 1.0, 3.0)    # non-integral: general sweep (total), valley search (bottleneck)
+    if k == 7: return cp.AffineHyperedgeCutModel(r(0, 3), r(0, 3), r(0, 3), r(2, 6), r(0, 3))            # b_self >= b_cut >= 0: bottleneck valley class
+    return cp.AffineHyperedgeCutModel(0.0, 0.5, 0.0, 0.7, 0.1)           # non-integral hyperedge: OUTSIDE the valley class (general sweep)
 
 
 t0 = time.time(); cases = 0
@@ -51,8 +53,9 @@ while time.time() - t0 < budget:
     A = rand_matrix(); f = rand_model(); K = int(rng.choice([1, 2, 3, 5, 8, 17]))
     tag = (A.m, A.n, A.nnz, type(f).__name__, f._params(), K)
     meths = [cp.DynamicTotalSplitter(f), cp.DynamicTotalChunker(f)]
-    if A.n <= 1500 or (all(p >= 0 for p in f._params()[1:]) and not isinstance(f, cp.AffineHyperedgeCutModel)):
-        meths += [cp.DynamicBottleneckSplitter(f)]          # (valley search for growing costs at any n; general sweep below 1500)
+    hyp_valley = isinstance(f, cp.AffineHyperedgeCutModel) and f.dtype == cp.models.CP_I64 and f._params()[3] >= f._params()[4] >= 0 and all(p >= 0 for p in f._params()[1:3])
+    if A.n <= 1500 or hyp_valley or (all(p >= 0 for p in f._params()[1:]) and not isinstance(f, cp.AffineHyperedgeCutModel)):
+        meths += [cp.DynamicBottleneckSplitter(f), cp.DynamicBottleneckChunker(f)]          # (valley search for growing costs at any n -- the wave walks; general sweep below 1500)
     if isinstance(f, (cp.AffineConnectivityModel, cp.AffineWorkModel)) and all(p >= 0 for p in f._params()) and sum(f._params()) > 0:
         meths += [cp.BisectCostBottleneckSplitter(f, 0.01), cp.BisectIndexBottleneckSplitter(f)]
         if isinstance(f, cp.AffineConnectivityModel):
@@ -65,8 +68,13 @@ while time.time() - t0 < budget:
     # windows from "barely feasible" to "wider than the matrix"
     if A.n >= 1 and A.n <= 2500:
         for w in (max(1, -(-A.n // K) + int(rng.integers(0, 4))), max(1, int(rng.integers(1, A.n + 3)))):
-            fc = cp.ConstrainedCost(f, cp.VertexCount(), w)
-            for meth in (cp.DynamicTotalSplitter(fc), cp.DynamicTotalChunker(fc)):
+            # the width weight under its own name, or as a work model alpha + c * width (windowed path too: csrc/capi.hip width_of_weight)
+            wk = int(rng.integers(0, 3))
+            c = int(rng.integers(1, 4)); a0 = int(rng.integers(0, 3))
+            fc = (cp.ConstrainedCost(f, cp.VertexCount(), w) if wk == 0 else
+                  cp.ConstrainedCost(f, cp.AffineWorkModel(a0, c, 0), a0 + c * w + int(rng.integers(0, c))) if wk == 1 else
+                  cp.ConstrainedCost(f, cp.AffineWorkModel(0.25 * a0, 0.5 * c, 0.0), 0.25 * a0 + 0.5 * c * w + 0.1))
+            for meth in (cp.DynamicTotalSplitter(fc), cp.DynamicTotalChunker(fc), cp.DynamicBottleneckSplitter(fc), cp.DynamicBottleneckChunker(fc)):
                 if meth.order == 1 and getattr(f, "alpha_k", None) is not None:
                     continue
                 got = cp.partition_stripe(A, K, meth, backend=hip)
@@ -81,6 +89,16 @@ while time.time() - t0 < budget:
                 got = cp.pack_stripe(A, meth, backend=hip)
                 want = cp.pack_stripe(A, meth, backend=orc)
                 assert got == want, ("pack", type(meth).__name__, w, tag)
+    # the batch entry points against their own loops
+    if cases % 7 == 0 and A.n >= 2:
+        wm = cp.AffineWorkModel(0, int(rng.integers(1, 5)), 1); nm = cp.AffineConnectivityModel(0, int(rng.integers(0, 5)), 1, int(rng.integers(1, 9)))
+        reqs = [(int(rng.choice([1, 2, 5, 9])), cp.BisectCostBottleneckSplitter(m, float(rng.choice([0.1, 0.01])))) for m in (wm, nm, wm, nm)]
+        for (Kb, m), g in zip(reqs, cp.partition_stripe_batch(A, reqs, backend=hip)):
+            assert g == cp.partition_stripe(A, Kb, m, backend=orc), ("bisect batch", tag)
+        cm = [cp.ConvexTotalChunker(cp.ConstrainedCost(cp.ColumnBlockComponentCostModel(int(rng.integers(1, 5)), lambda x: 1 + x), cp.VertexCount(), int(rng.integers(1, 16)))) for _ in range(3)]
+        if A.n <= 3000:
+            for m, g in zip(cm, cp.pack_stripe_batch(A, cm, backend=hip)):
+                assert g == cp.pack_stripe(A, m, backend=orc), ("convex batch", tag)
     cases += 1
     if cases % 5 == 0:
         print("  %d cases, %.0f s" % (cases, time.time() - t0), flush=True)
