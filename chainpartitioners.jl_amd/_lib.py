@@ -249,13 +249,14 @@ class HipBackend:
                                         _p(cst) if mm.struct.dtype == M.CP_F64 else None)
         return rc, ptr.T, cst.T
 
-    def dynamic_tables_constrained(self, A, K, mm, wmax, combine=0):
-        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of Dynamic{Total,Bottleneck}Splitter(ConstrainedCost(f, VertexCount(), wmax))
-        (combine 0 = total, 1 = bottleneck)"""
+    def dynamic_tables_constrained(self, A, K, mm, wmax, combine=0, wm=None):
+        """(rc, j'_lo[K], j'_hi[K], ptr[j', k], cst[j', k]) of Dynamic{Total,Bottleneck}Splitter(ConstrainedCost(f, w, wmax))
+        (combine 0 = total, 1 = bottleneck; wm: the marshalled weight, None = VertexCount())"""
         ptr = np.zeros((K, A.n + 1), dtype=np.int64)
         cst = np.zeros((K, A.n + 1), dtype=np.int64 if mm.struct.dtype == M.CP_I64 else np.float64)
         lo = np.zeros(K, dtype=np.int64); hi = np.zeros(K, dtype=np.int64)
-        rc = self.lib.cp_dynamic_tables_constrained_combine(self._h(A), _i64(K), C.c_int32(combine), mm.ptr, _i64(wmax), _p(lo), _p(hi), _p(ptr),
+        rc = self.lib.cp_dynamic_tables_constrained_combine(self._h(A), _i64(K), C.c_int32(combine), mm.ptr, wm.ptr if wm is not None else None,
+                                                            _i64(int(wmax)), C.c_double(float(wmax)), _p(lo), _p(hi), _p(ptr),
                                                             _p(cst) if mm.struct.dtype == M.CP_I64 else None,
                                                             _p(cst) if mm.struct.dtype == M.CP_F64 else None)
         return rc, lo, hi, ptr.T, cst.T

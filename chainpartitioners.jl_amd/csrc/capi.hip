@@ -282,16 +282,67 @@ static void width_windows(int64_t n, int64_t K, int64_t w, std::vector<int64_t> 
 // the layer's candidate limits directly (no masked row: the crossing is searched inside [max(lo[k-1], j' - w), min(j', hi[k-1])],
 // where the previous layer's costs are finite and still grow with the prefix -- dropping the last column of a feasible prefix
 // keeps every width <= w).
+// Any monotone weight w(j, j') = alpha + b_v (j' - j) + b_p (pos[j'] - pos[j]) with b_v, b_p >= 0 (AffineWorkModel: pins per part,
+// work per part): the part [j, j') fits iff j >= j0(j'), the first column whose part up to j' fits -- non-decreasing in j'.  The
+// reference finds it by advancing j0 while w(j0, j', k) > w_max (DynamicSplitter.jl:235-237); with a monotone weight that is this
+// array, found by bisection in the weight's own arithmetic (WorkCosts.jl:17).  j0[r] (0-based row r = j' - 1, 0-based column),
+// r + 1 when not even the empty part fits.
+template <typename TW>
+__global__ void __launch_bounds__(256) k_weight_j0(int64_t n, const int64_t *__restrict__ pos, TW alpha, TW bv, TW bp, TW wmax, int32_t *__restrict__ j0)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    const int64_t pr = pos[r];
+    auto fits = [&](int64_t p) { return cadd(cadd(alpha, cmulc(r - p, bv)), cmulc(pr - pos[p], bp)) <= wmax; };
+    int64_t lo = 0, hi = r + 1;                            // first p in [0, r] that fits; r + 1: none
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (fits(mid)) hi = mid; else lo = mid + 1; }
+    j0[r] = (int32_t)lo;
+}
+
+// column_constraints (DynamicSplitter.jl:144-172) from that array: j'_lo walks back from n + 1 (:150-158, the first step taken
+// unconditionally), j'_hi forward from 1 (:161-169).  1-based j', as the reference's vectors.
+static void weight_windows(int64_t n, int64_t K, const std::vector<int32_t> &j0, std::vector<int64_t> &lo, std::vector<int64_t> &hi)
+{
+    lo.assign((size_t)K + 1, 0); hi.assign((size_t)K + 1, 0);
+    int64_t jp = n + 1;
+    for (int64_t k = K; k >= 1; k--) { lo[(size_t)k] = jp; jp = std::min<int64_t>(jp, (int64_t)j0[(size_t)jp - 1] + 1); }
+    int64_t j = 1;
+    for (int64_t k = 1; k <= K; k++) {
+        // the largest j' >= j with j0(j') <= j: j0 is non-decreasing in j'
+        const int64_t fit = (int64_t)(std::upper_bound(j0.begin(), j0.end(), (int32_t)(j - 1)) - j0.begin());     // #rows with j0 <= j - 1 (0-based) = the largest such j' (1-based)
+        hi[(size_t)k] = std::max<int64_t>(j, fit);
+        j = hi[(size_t)k];
+    }
+}
+
 template <typename TC>
 static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const cp_model_t *mdl, int64_t wmax,
                                     int64_t *spl_out, int64_t *ptr_tab, TC *cst_tab, int64_t *win_lo, int64_t *win_hi,
-                                    int32_t combine = CP_COMBINE_SUM)
+                                    int32_t combine = CP_COMBINE_SUM, const cp_model_t *weight = nullptr, int64_t wmax_i64 = 0, double wmax_f64 = 0)
 {
     hipStream_t s = A->stream;
     const int64_t n = A->n;
     const size_t n1 = (size_t)n + 1;
     std::vector<int64_t> lo, hi;
-    width_windows(n, K, wmax, lo, hi);
+    DBuf<int32_t> j0;
+    if (weight) {                                                        // a general monotone weight (bottleneck only): its j0 array
+        CP_REQUIRE(combine == CP_COMBINE_MAX && weight->kind == CP_MODEL_WORK && !weight->alpha_k, CP_EINTERNAL, "general weights: bottleneck DP only");
+        j0.alloc(n1);
+        const unsigned gw = (unsigned)cdiv((int64_t)n1, 256);
+        if (weight->dtype == CP_I64)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_weight_j0<int64_t>), dim3(gw), dim3(256), 0, s, n, A->pos.p, weight->p_i64[CP_P_ALPHA],
+                               weight->p_i64[CP_P_VERTEX], weight->p_i64[CP_P_PIN], wmax_i64, j0.p);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_weight_j0<double>), dim3(gw), dim3(256), 0, s, n, A->pos.p, weight->p_f64[CP_P_ALPHA],
+                               weight->p_f64[CP_P_VERTEX], weight->p_f64[CP_P_PIN], wmax_f64, j0.p);
+        CP_HIP(hipGetLastError());
+        std::vector<int32_t> hj(n1);
+        CP_HIP(hipMemcpyAsync(hj.data(), j0.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, s));
+        CP_HIP(hipStreamSynchronize(s));
+        weight_windows(n, K, hj, lo, hi);
+    } else {
+        width_windows(n, K, wmax, lo, hi);
+    }
     if (win_lo) for (int64_t k = 1; k <= K; k++) { win_lo[k - 1] = lo[(size_t)k]; win_hi[k - 1] = hi[(size_t)k]; }
     if (ptr_tab) for (size_t i = 0; i < (size_t)K * n1; i++) { ptr_tab[i] = 0; cst_tab[i] = CostTraits<TC>::typemax(); }
     if (hi[(size_t)K] < n + 1) {                                         // infeasible (:217-222): a degenerate partition, no exception
@@ -299,7 +350,7 @@ static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const
         spl_out[K] = n + 1;
         return CP_INFEASIBLE;
     }
-    const int64_t w = std::min<int64_t>(wmax, std::max<int64_t>(n, 1));     // (wider than the matrix: every window is [0, r])
+    const int64_t w = weight ? 0 : std::min<int64_t>(wmax, std::max<int64_t>(n, 1));     // (wider than the matrix: every window is [0, r])
     const bool need_self = mdl->kind == CP_MODEL_HYPEREDGE_CUT;
     ensure_links(A);
     if (need_self) ensure_self(A);
@@ -339,7 +390,7 @@ static int32_t run_dynamic_windowed(cp_csr_s *A, int64_t K, int32_t order, const
             dp_total_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, work, lo[(size_t)k] - 1, hi[(size_t)k] - 1, w);
         else
             dp_bottleneck_layer<TC>(A, HM.d, alpha_of(k), Wm.p, cst.p, ptr.p + (size_t)(k - 1) * n1, lo[(size_t)k] - 1, hi[(size_t)k] - 1,
-                                    w, lo[(size_t)k - 1] - 1, hi[(size_t)k - 1] - 1);
+                                    w, lo[(size_t)k - 1] - 1, hi[(size_t)k - 1] - 1, weight ? j0.p : nullptr);
         dump_layer(k);
     }
     // unravel_splits (DynamicSplitter.jl:89-99); every visited cell lies in its layer's window
@@ -389,6 +440,13 @@ static int64_t width_of_weight(const cp_model_t *w, int64_t n, int64_t wmax_i64,
     if (fits(hi)) return hi;
     while (hi - lo > 1) { const int64_t mid = lo + ((hi - lo) >> 1); if (fits(mid)) lo = mid; else hi = mid; }
     return lo;
+}
+
+// AffineWorkModel(alpha, b_v, b_p) with b_v, b_p >= 0: grows with its part (k_weight_j0)
+static bool monotone_work_weight(const cp_model_t *w)
+{
+    if (!w || w->kind != CP_MODEL_WORK || w->alpha_k) return false;
+    return w->dtype == CP_I64 ? (w->p_i64[CP_P_VERTEX] >= 0 && w->p_i64[CP_P_PIN] >= 0) : (w->p_f64[CP_P_VERTEX] >= 0 && w->p_f64[CP_P_PIN] >= 0);
 }
 
 // ------------------------------------------------------------------ row-tiled DP (one rank = one tile of rows per layer)
@@ -743,6 +801,9 @@ int32_t cp_partition_dynamic(cp_csr_t A, int64_t K, int32_t combine, int32_t ord
                 if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr, combine);
                 return run_dynamic_windowed<double>(A, K, order, model, wv, spl_out, nullptr, nullptr, nullptr, nullptr, combine);
             }
+            // bottleneck under any monotone work weight (pins, vertices + pins): the valley search with the weight's j0 array
+            if (combine == CP_COMBINE_MAX && wv == -2 && monotone_work_weight(weight) && model->dtype == CP_I64 && windowed_ok(A, K, combine, model, &vc, 1))
+                return run_dynamic_windowed<int64_t>(A, K, order, model, 0, spl_out, nullptr, nullptr, nullptr, nullptr, combine, weight, wmax_i64, wmax_f64);
             if (model->dtype == CP_I64) return run_dyn_constrained<int64_t>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
             return run_dyn_constrained<double>(A, K, combine, order, model, Pi, weight, wmax_i64, wmax_f64, spl_out);
         }
@@ -771,25 +832,31 @@ int32_t cp_dynamic_tables(cp_csr_t A, int64_t K, int32_t combine, const cp_model
     });
 }
 
-int32_t cp_dynamic_tables_constrained_combine(cp_csr_t A, int64_t K, int32_t combine, const cp_model_t *model, int64_t wmax,
-                                              int64_t *win_lo, int64_t *win_hi, int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
+int32_t cp_dynamic_tables_constrained_combine(cp_csr_t A, int64_t K, int32_t combine, const cp_model_t *model, const cp_model_t *weight,
+                                              int64_t wmax_i64, double wmax_f64, int64_t *win_lo, int64_t *win_hi, int64_t *ptr_out,
+                                              int64_t *cst_i64, double *cst_f64)
 {
     return guarded([&]() -> int32_t {
         CP_REQUIRE(A && ptr_out && win_lo && win_hi && model_known(model) && K >= 1, CP_EINVAL, "bad argument");
         CP_REQUIRE(combine == CP_COMBINE_SUM || combine == CP_COMBINE_MAX, CP_EINVAL, "bad combine");
+        CP_REQUIRE(!weight || weight->kind == CP_MODEL_VERTEX_COUNT || (weight->kind == CP_MODEL_WORK && !weight->alpha_k), CP_EINVAL,
+                   "weight must be VertexCount or an AffineWorkModel");
         cp_model_t vc{}; vc.kind = CP_MODEL_VERTEX_COUNT; vc.dtype = CP_I64;
-        CP_REQUIRE(windowed_ok(A, K, combine, model, &vc, wmax), CP_EUNSUPPORTED, "outside the windowed scalable path");
+        const int64_t wv = weight ? width_of_weight(weight, A->n, wmax_i64, wmax_f64) : wmax_i64;      // (null: the width weight)
+        const bool general = wv == -2 && combine == CP_COMBINE_MAX && monotone_work_weight(weight) && model->dtype == CP_I64;
+        CP_REQUIRE(windowed_ok(A, K, combine, model, &vc, general ? 1 : wv), CP_EUNSUPPORTED, "outside the windowed scalable path");
         CP_HIP(hipSetDevice(A->device));
         std::vector<int64_t> spl((size_t)K + 1);
-        if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_i64, win_lo, win_hi, combine);
-        return run_dynamic_windowed<double>(A, K, CP_ORDER_SPLITTER, model, wmax, spl.data(), ptr_out, cst_f64, win_lo, win_hi, combine);
+        if (general) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, 0, spl.data(), ptr_out, cst_i64, win_lo, win_hi, combine, weight, wmax_i64, wmax_f64);
+        if (model->dtype == CP_I64) return run_dynamic_windowed<int64_t>(A, K, CP_ORDER_SPLITTER, model, wv, spl.data(), ptr_out, cst_i64, win_lo, win_hi, combine);
+        return run_dynamic_windowed<double>(A, K, CP_ORDER_SPLITTER, model, wv, spl.data(), ptr_out, cst_f64, win_lo, win_hi, combine);
     });
 }
 
 int32_t cp_dynamic_tables_constrained(cp_csr_t A, int64_t K, const cp_model_t *model, int64_t wmax, int64_t *win_lo, int64_t *win_hi,
                                       int64_t *ptr_out, int64_t *cst_i64, double *cst_f64)
 {
-    return cp_dynamic_tables_constrained_combine(A, K, CP_COMBINE_SUM, model, wmax, win_lo, win_hi, ptr_out, cst_i64, cst_f64);
+    return cp_dynamic_tables_constrained_combine(A, K, CP_COMBINE_SUM, model, nullptr, wmax, (double)wmax, win_lo, win_hi, ptr_out, cst_i64, cst_f64);
 }
 
 int32_t cp_oracle_eval(cp_csr_t A, const cp_model_t *model, const cp_rowpart_t *Pi, int32_t hint, int64_t nq,

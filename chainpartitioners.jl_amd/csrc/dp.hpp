@@ -25,8 +25,9 @@ void dp_brute_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, int32_t combin
 template <typename TC>
 void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
                          int64_t r_lo, int64_t r_hi,
-                         // candidate limits of a width-constrained layer (0-based; defaults: none): row r takes max(p_lo0, r - wwin) <= p <= min(r, p_hi0)
-                         int64_t wwin = 0, int64_t p_lo0 = 0, int64_t p_hi0 = -1);
+                         // candidate limits of a weight-constrained layer (0-based; defaults: none): row r takes max(p_lo0, j0(r)) <= p <= min(r, p_hi0),
+                         // j0(r) = r - wwin, or j0[r] when the device array j0 (n + 1 entries) is given
+                         int64_t wwin = 0, int64_t p_lo0 = 0, int64_t p_hi0 = -1, const int32_t *j0 = nullptr);
 extern int64_t g_opt_bn_wave, g_opt_bn_run, g_opt_bn_slack;    // wave-per-run walk (default) and its rows per wave
 extern int64_t g_opt_bn_chunk;                 // rows per two-pointer walk (one lane each)
 

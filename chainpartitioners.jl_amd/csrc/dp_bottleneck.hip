@@ -45,9 +45,11 @@ struct BnCtx {
     DevModel<TC> M; TC alpha;
     int64_t n; int32_t hyp;
     int64_t N, NF;                       // lengths of the link arrays (next / prev) and of the row buckets (flast / lfirst)
-    // candidate limits of a width-constrained layer (DynamicSplitter.jl:233-246; 0-based): row r takes max(p_lo0, r - wwin) <= p <=
-    // min(r, p_hi0); unconstrained: wwin = 0 (no lower cut), p_lo0 = 0, p_hi0 = n
+    // candidate limits of a weight-constrained layer (DynamicSplitter.jl:233-246; 0-based): row r takes max(p_lo0, j0(r)) <= p <=
+    // min(r, p_hi0) with j0(r) = r - wwin (width weights) or j0[r] (any monotone weight: the first column whose part up to r fits);
+    // unconstrained: wwin = 0, j0 = null (no lower cut), p_lo0 = 0, p_hi0 = n
     int64_t wwin, p_lo0, p_hi0;
+    const int32_t *j0;
     const int64_t *pos, *lpos;
     const int32_t *pos32, *prev, *next, *fpos32, *flast, *lpos32, *lfirst;
     WaveletDev net, self;
@@ -110,7 +112,8 @@ __global__ void __launch_bounds__(1024) k_bn_run3(int64_t n1, int64_t nblk, int3
 template <typename TC> __device__ __forceinline__ int64_t bn_plo(const BnCtx<TC> &C, int64_t r)
 {
     int64_t lo = C.p_lo0;
-    if (C.wwin > 0 && r - C.wwin > lo) lo = r - C.wwin;
+    if (C.j0) { const int64_t j = C.j0[r]; if (j > lo) lo = j; }
+    else if (C.wwin > 0 && r - C.wwin > lo) lo = r - C.wwin;
     return lo;
 }
 template <typename TC> __device__ __forceinline__ int64_t bn_phi(const BnCtx<TC> &C, int64_t r) { return r < C.p_hi0 ? r : C.p_hi0; }
@@ -526,7 +529,7 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
             }
         }
         const TC rowpart = cadd(cadd(C.alpha, cmulc((int64_t)r, kV)), cmulc((int64_t)posr, kP));
-        const int32_t plo_r = (int32_t)bn_plo(C, (int64_t)r), phi_r = (int32_t)bn_phi(C, (int64_t)r);      // this row's candidates [plo_r, phi_r]
+        const int32_t plo_r = (int32_t)bn_plo(C, (int64_t)rq), phi_r = (int32_t)bn_phi(C, (int64_t)rq);     // this row's candidates [plo_r, phi_r]
         // ---- windows of 64 columns from cs - 1 on
         int32_t c = cs, c_carry = cs;
         bool open = valid, have_fm = false, have_prev = false;
@@ -725,7 +728,7 @@ int64_t g_opt_bn_run = 253;       // ... rows per wave (1 + 63 m: m sub-runs of 
 
 template <typename TC>
 void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, TC *cst_out, int32_t *ptr_out,
-                         int64_t rlo, int64_t rhi, int64_t wwin, int64_t p_lo0, int64_t p_hi0)
+                         int64_t rlo, int64_t rhi, int64_t wwin, int64_t p_lo0, int64_t p_hi0, const int32_t *j0)
 {
     hipStream_t s = A->stream;
     const int64_t n = A->n, n1 = n + 1;
@@ -739,7 +742,8 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     BnCtx<TC> C;
     C.M = M; C.alpha = alpha; C.n = n; C.hyp = hyp ? 1 : 0;
     C.N = A->N; C.NF = hyp ? A->nrows_nonempty : 0;
-    const bool limited = wwin > 0 || p_lo0 > 0 || (p_hi0 >= 0 && p_hi0 < n);
+    const bool limited = wwin > 0 || j0 || p_lo0 > 0 || (p_hi0 >= 0 && p_hi0 < n);
+    C.j0 = j0;
     C.wwin = wwin > 0 ? wwin : 0; C.p_lo0 = p_lo0 > 0 ? p_lo0 : 0; C.p_hi0 = (p_hi0 >= 0 && p_hi0 < n) ? p_hi0 : n;
     CP_REQUIRE(!limited || (g_opt_bn_wave >= 2 && CostTraits<TC>::is_int), CP_EINTERNAL, "candidate limits need the searched-crossings walk (Int64 costs)");
     C.pos = A->pos.p; C.lpos = hyp ? A->lpos.p : nullptr;
@@ -805,7 +809,7 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     CP_HIP(hipGetLastError());
 }
 
-template void dp_bottleneck_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t);
-template void dp_bottleneck_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t);
+template void dp_bottleneck_layer<int64_t>(cp_csr_s *, const DevModel<int64_t> &, int64_t, const int64_t *, int64_t *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t *);
+template void dp_bottleneck_layer<double>(cp_csr_s *, const DevModel<double> &, double, const double *, double *, int32_t *, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t *);
 
 }  // namespace cpk

@@ -186,10 +186,12 @@ int32_t cp_dynamic_tables(cp_csr_t csr, int64_t K, int32_t combine, const cp_mod
 int32_t cp_dynamic_tables_constrained(cp_csr_t csr, int64_t K, const cp_model_t *model, int64_t wmax,
                                       int64_t *win_lo /* K */, int64_t *win_hi /* K */,
                                       int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
-/* ... with the combine op given: CP_COMBINE_MAX is DynamicBottleneckSplitter(ConstrainedCost(f, VertexCount(), w_max))
- * (DynamicSplitter.jl:206-258 with g = max), on the valley search with candidate limits (Int64 models). */
-int32_t cp_dynamic_tables_constrained_combine(cp_csr_t csr, int64_t K, int32_t combine, const cp_model_t *model, int64_t wmax,
-                                              int64_t *win_lo /* K */, int64_t *win_hi /* K */,
+/* ... with the combine op and the weight given (NULL: VertexCount).  CP_COMBINE_MAX is DynamicBottleneckSplitter(ConstrainedCost(f,
+ * w, w_max)) (DynamicSplitter.jl:206-258 with g = max) on the valley search with candidate limits: Int64 cost models; width
+ * weights (VertexCount, AffineWorkModel(alpha, c, 0)) or any AffineWorkModel weight with b_v, b_p >= 0 (pins per part).
+ * CP_COMBINE_SUM takes width weights only.  w_max in the weight's element type, as in cp_partition_dynamic. */
+int32_t cp_dynamic_tables_constrained_combine(cp_csr_t csr, int64_t K, int32_t combine, const cp_model_t *model, const cp_model_t *weight,
+                                              int64_t wmax_i64, double wmax_f64, int64_t *win_lo /* K */, int64_t *win_hi /* K */,
                                               int64_t *ptr_out, int64_t *cst_i64, double *cst_f64);
 
 /* ---- row-tiled DP: one process per GPU, the layer's cost vector is completed by the caller's collective ----

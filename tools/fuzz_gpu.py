@@ -69,11 +69,13 @@ while time.time() - t0 < budget:
     if A.n >= 1 and A.n <= 2500:
         for w in (max(1, -(-A.n // K) + int(rng.integers(0, 4))), max(1, int(rng.integers(1, A.n + 3)))):
             # the width weight under its own name, or as a work model alpha + c * width (windowed path too: csrc/capi.hip width_of_weight)
-            wk = int(rng.integers(0, 3))
+            wk = int(rng.integers(0, 4))
             c = int(rng.integers(1, 4)); a0 = int(rng.integers(0, 3))
+            # wk 3: a pin-weighted budget (the bottleneck DP takes it on the valley search through the weight's j0 array)
             fc = (cp.ConstrainedCost(f, cp.VertexCount(), w) if wk == 0 else
                   cp.ConstrainedCost(f, cp.AffineWorkModel(a0, c, 0), a0 + c * w + int(rng.integers(0, c))) if wk == 1 else
-                  cp.ConstrainedCost(f, cp.AffineWorkModel(0.25 * a0, 0.5 * c, 0.0), 0.25 * a0 + 0.5 * c * w + 0.1))
+                  cp.ConstrainedCost(f, cp.AffineWorkModel(0.25 * a0, 0.5 * c, 0.0), 0.25 * a0 + 0.5 * c * w + 0.1) if wk == 2 else
+                  cp.ConstrainedCost(f, cp.AffineWorkModel(a0, c - 1, 1), a0 + (c - 1) * w + int(w * max(A.nnz, 1) / max(A.n, 1)) + int(rng.integers(0, 5))))
             for meth in (cp.DynamicTotalSplitter(fc), cp.DynamicTotalChunker(fc), cp.DynamicBottleneckSplitter(fc), cp.DynamicBottleneckChunker(fc)):
                 if meth.order == 1 and getattr(f, "alpha_k", None) is not None:
                     continue
