@@ -18,6 +18,9 @@ what the reference's `@benchmarkable partition_stripe($A,$K,$f)` times, test/run
               O(n log^2 n) path admits the diagonal candidate ties the minimum); all K layers are computed.
   constrained DynamicTotalSplitter(ConstrainedCost(the same cost, VertexCount(), ceil(1.5 n / K))) -- the reference's own script
               (bin/test_table_constrained_splits.jl:28) -- on the same matrix: a non-trivial answer on the windowed path.
+  constrained-bottleneck  DynamicBottleneckSplitter(ConstrainedCost(AffineConnectivityModel(0,10,1,100), w, w_max)) on the same matrix:
+              --weight width: VertexCount(), w_max = ceil(1.5 n / K) (the factor of bin/test_table_constrained_splits.jl:28);
+              --weight pins: AffineWorkModel(0,0,1), w_max = ceil(1.5 nnz / K).  Valley search with candidate limits (csrc/dp_bottleneck.hip).
   bottleneck  DynamicBottleneckSplitter(AffineConnectivityModel(0,10,1,100)), K = 64, same matrix; cross-checked at full size
               against BisectIndexBottleneckSplitter (exact).
   2           BisectCostBottleneckSplitter(AffineWorkModel(0,10,1) / AffineConnectivityModel(0,10,1,100), 0.01), n = 10^6, K = 32.
@@ -204,21 +207,28 @@ class DpBench:
         torch.cuda.synchronize()
         self.h = self.hip.csr_from_device(self.n, self.n, self.N, self.colptr.data_ptr(), self.rowval.data_ptr())
         cp = self.cp
-        self.combine, self.wm, self.w = 0, None, 0
+        self.combine, self.wm, self.w, self.wmodel, self.wname = 0, None, 0, None, ""
         if cfg in ("3", "constrained"):
             self.mdl = cp.AffineConnectivityModel(0, 0, 0, 1); self.mname = "AffineConnectivityModel{Int64}(0,0,0,1)"
-        elif cfg == "bottleneck":
+        elif cfg in ("bottleneck", "constrained-bottleneck"):
             self.mdl = cp.AffineConnectivityModel(0, 10, 1, 100); self.mname = "AffineConnectivityModel{Int64}(0,10,1,100)"; self.combine = 1
         else:
             self.mdl = cp.AffineHyperedgeCutModel(0, 0, 0, 0, 1); self.mname = "AffineHyperedgeCutModel{Int64}(0,0,0,0,1)"
         if cfg == "constrained":
-            self.wm = cp.VertexCount().marshal(); self.w = -(-3 * self.n // (2 * self.K))
+            self.wmodel, self.wname = cp.VertexCount(), "VertexCount()"; self.w = -(-3 * self.n // (2 * self.K))
+        elif cfg == "constrained-bottleneck":
+            if getattr(args, "weight", "width") == "pins":
+                self.wmodel, self.wname = cp.AffineWorkModel(0, 0, 1), "AffineWorkModel{Int64}(0,0,1)"; self.w = -(-3 * self.N // (2 * self.K))
+            else:
+                self.wmodel, self.wname = cp.VertexCount(), "VertexCount()"; self.w = -(-3 * self.n // (2 * self.K))
+        if self.wmodel is not None:
+            self.wm = self.wmodel.marshal()
         self.mm = self.mdl.marshal()
         self.spl = np.zeros(self.K + 1, dtype=np.int64)
 
     def method_name(self):
-        if self.cfg == "constrained":
-            return "DynamicTotalSplitter(ConstrainedCost(%s, VertexCount(), %d))" % (self.mname, self.w)
+        if self.wmodel is not None:
+            return "Dynamic%sSplitter(ConstrainedCost(%s, %s, %d))" % ("Bottleneck" if self.combine else "Total", self.mname, self.wname, self.w)
         return ("DynamicBottleneckSplitter(%s)" if self.combine else "DynamicTotalSplitter(%s)") % self.mname
 
     def step(self):
@@ -226,7 +236,7 @@ class DpBench:
         hip.reset_cache(h)           # every step rebuilds the oracle structures, as one reference call does
         if self.tiled:
             from chainpartitioners_jl_amd.distributed import partition_stripe_tiled
-            cost = self.cp.ConstrainedCost(self.mdl, self.cp.VertexCount(), self.w) if self.cfg == "constrained" else self.mdl
+            cost = self.cp.ConstrainedCost(self.mdl, self.wmodel, self.w) if self.wmodel is not None else self.mdl
             meth = self.cp.DynamicBottleneckSplitter(cost) if self.combine else self.cp.DynamicTotalSplitter(cost)
             self.spl[:] = partition_stripe_tiled(hip, h, self.n, self.K, meth, device=self.dev)
             return
@@ -254,8 +264,27 @@ class DpBench:
             rc = hip.partition_bisect_index(self.h, K, self.mm, 0, bi)
             assert rc == 0
             rc, obj_bi = hip.objective(self.h, K, bi, self.mm, None, 1)
-            assert obj == obj_bi, (obj, obj_bi)                               # the DP optimum == the exact BisectIndex optimum
             info["bisect_index_bottleneck"] = int(obj_bi)
+            if self.wmodel is None:
+                assert obj == obj_bi, (obj, obj_bi)                           # the DP optimum == the exact BisectIndex optimum
+            else:
+                # every part within its budget; no better than the unconstrained optimum; no worse than a feasible partition
+                # (greedy parts filled to the budget, the columns' pin counts read back from the resident colptr)
+                colptr = self.colptr.cpu().numpy().astype(np.int64)
+                wgt = (np.diff(spl) if self.wname == "VertexCount()" else colptr[spl[1:] - 1] - colptr[spl[:-1] - 1])
+                assert int(wgt.max()) <= self.w, (int(wgt.max()), self.w)
+                assert obj >= obj_bi
+                if self.wname == "VertexCount()":
+                    greedy = np.minimum(1 + self.w * np.arange(K + 1, dtype=np.int64), n + 1)
+                else:
+                    greedy = np.ones(K + 1, dtype=np.int64)
+                    for k in range(1, K + 1):                     # the furthest column whose pins still fit
+                        greedy[k] = min(n + 1, int(np.searchsorted(colptr, colptr[greedy[k - 1] - 1] + self.w, side="right")))
+                assert greedy[-1] == n + 1
+                rc, obj_gr = hip.objective(self.h, K, greedy, self.mm, None, 1)
+                assert obj <= obj_gr, (obj, obj_gr)
+                info.update({"max_part_weight": int(wgt.max()), "w_max": int(self.w), "objective_of_greedy_full_parts": int(obj_gr),
+                             "unconstrained_answer_feasible": bool(obj == obj_bi)})
         else:
             assert obj >= whole                                               # sum_k nets_k >= nets(all columns)
         return info
@@ -319,7 +348,14 @@ def dp_cpu_baseline(B, cfg, sizes):
     n, N, K = B.n, B.N, B.K
     Kfit = min(K, 64)                    # (the law is linear in K: a is fitted with at most 64 parts, stated in `sample`)
     avg_deg = N / n
-    if cfg == "constrained":
+    if cfg == "constrained-bottleneck":
+        pins = B.wname != "VertexCount()"
+        mk = lambda cp, nn: cp.DynamicBottleneckSplitter(cp.ConstrainedCost(B.mdl, B.wmodel, -(-3 * (int(nn * avg_deg) if pins else nn) // (2 * Kfit))))
+        a, samples = cpu_fit_quadratic(mk, Kfit, avg_deg, SEED + 2, sizes=sizes, per_k=False)
+        t_full = a * float(n) * float(n)
+        law = ("t = a*n^2 with a=%.3e s (as for the constrained total DP: the rows of layer k's window, each over at most one budget of candidates "
+               "-- Theta(n w K / 2) = Theta(n^2) steps whatever K)" % a)
+    elif cfg == "constrained":
         mk = lambda cp, nn: cp.DynamicTotalSplitter(cp.ConstrainedCost(B.mdl, cp.VertexCount(), -(-3 * nn // (2 * Kfit))))
         a, samples = cpu_fit_quadratic(mk, Kfit, avg_deg, SEED + 2, sizes=sizes, per_k=False)
         t_full = a * float(n) * float(n)
@@ -638,7 +674,8 @@ def dry_run(args, rank, world, dist):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="3", choices=["3", "constrained", "bottleneck", "2", "4", "5", "5shape"])
+    ap.add_argument("--config", default="3", choices=["3", "constrained", "bottleneck", "constrained-bottleneck", "2", "4", "5", "5shape"])
+    ap.add_argument("--weight", choices=["width", "pins"], default="width", help="config constrained-bottleneck: the weight of the ConstrainedCost")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)

@@ -53,3 +53,18 @@ def test_constrained_line_matches_the_oracle_and_is_not_degenerate(orc):
     f = cp.ConstrainedCost(cp.AffineConnectivityModel(0, 0, 0, 1), cp.VertexCount(), -(-3 * n // (2 * K)))
     want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=orc)
     assert d["check"]["spl"] == want.spl.tolist() and len(set(want.spl.tolist())) > 2
+
+
+@pytest.mark.parametrize("weight", ["width", "pins"])
+def test_constrained_bottleneck_line_matches_the_oracle(orc, weight):
+    """`--config constrained-bottleneck [--weight pins]` at an oracle size: the valley search with candidate limits through the bench entry"""
+    n, K = 6000, 16
+    d = _bench("--config", "constrained-bottleneck", "--weight", weight, "--n", str(n), "--nnz", str(10 * n), "--parts", str(K), "--steps", "1",
+               "--warmup", "1", "--no-cpu-baseline", "--emit-spl")
+    _, _, colptr, rowval = synth.suitesparse_shaped_np(n, 10, SEED + 3 - 1, nnz=10 * n)
+    A = cp.SparseMatrixCSC(n, n, colptr, rowval)
+    wgt, budget = (cp.VertexCount(), -(-3 * n // (2 * K))) if weight == "width" else (cp.AffineWorkModel(0, 0, 1), -(-3 * A.nnz // (2 * K)))
+    f = cp.ConstrainedCost(cp.AffineConnectivityModel(0, 10, 1, 100), wgt, budget)
+    want = cp.partition_stripe(A, K, cp.DynamicBottleneckSplitter(f), backend=orc)
+    assert d["check"]["spl"] == want.spl.tolist() and len(set(want.spl.tolist())) == K + 1
+    assert d["check"]["max_part_weight"] <= d["check"]["w_max"] == budget
