@@ -1893,17 +1893,39 @@ __global__ void __launch_bounds__(256) k_combine_win(int lvl, Geo G, int64_t n, 
 }
 
 // ---- anchors of the mirrored head tasks (windowed layers), once per (pattern, w)
-// hist[e]++ for e = min(next[q], col[q] + w, n): then  nets(max(0, r - w), r) = pos[r] - #{q : e(q) < r}   (an entry is counted by
+// hist[e] = #{q : e(q) = e}, e(q) = min(next[q], col[q] + w, n): then  nets(max(0, r - w), r) = pos[r] - #{q : e(q) < r}   (an entry is counted by
 // the window ending before r iff it lies in a column < r, is the LAST occurrence of its row before r, and its column is >= r - w)
-__global__ void __launch_bounds__(256) k_win_hist(int64_t N, int64_t n, int64_t w, const int32_t *__restrict__ col, const int32_t *__restrict__ next,
-                                                  int32_t *__restrict__ hist)
+// Without atomics (10^8 scattered atomic adds took 12.5 ms; this takes the time of two column passes): the entries with e = x are
+//   * next[q] = x <= col[q] + w : one per entry q' of COLUMN x whose previous occurrence is within the window, prev[q'] >= max(0, x - w);
+//   * col[q] + w = x < next[q]  : the entries of column x - w that do not come back by column x;
+// one lane per column x < n (hist[n] is never read: E[r] sums the values below r <= n), eight loads in flight.
+__global__ void __launch_bounds__(256) k_win_hist(int64_t n, int64_t w, const int32_t *__restrict__ pos, const int32_t *__restrict__ prev,
+                                                  const int32_t *__restrict__ next, int32_t *__restrict__ hist)
 {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
-    int64_t e = (int64_t)col[q] + w, nx = next[q];
-    if (nx < e) e = nx;
-    if (e > n) e = n;
-    atomicAdd(&hist[e], 1);
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > n) return;
+    int32_t c = 0;
+    if (x < n) {
+        const int32_t lo = (int32_t)(x > w ? x - w : 0);
+        for (int32_t q = pos[x], q1 = pos[x + 1]; q < q1; q += 8) {
+            int32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = q + k < q1 ? prev[q + k] : -1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) c += (v[k] >= lo);
+        }
+        if (x >= w) {
+            const int32_t xx = (int32_t)x;
+            for (int32_t q = pos[x - w], q1 = pos[x - w + 1]; q < q1; q += 8) {
+                int32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = q + k < q1 ? next[q + k] : INT32_MIN;
+#pragma unroll
+                for (int k = 0; k < 8; k++) c += (v[k] > xx);
+            }
+        }
+    }
+    hist[x] = c;
 }
 // the same for whole rows (self nets): rows with first >= r - w and last < r  =  #{last < r} - #{max(last, first + w) < r}
 __global__ void __launch_bounds__(256) k_win_hist_rows(int64_t m, int64_t n, int64_t w, const int32_t *__restrict__ rfirst, const int32_t *__restrict__ rlast,
@@ -2118,8 +2140,9 @@ template <typename TC, bool HYP, bool MIR>
 __global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restrict__ cnt, const int32_t *__restrict__ cnt2,
                                                  const int32_t *__restrict__ pos, const TC *__restrict__ W, DevModel<TC> M, TC alpha,
                                                  int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt,
-                                                 Best<TC, HYP> *__restrict__ part, int64_t tile0, int64_t tile1)
+                                                 Best<TC, HYP> *__restrict__ part, int64_t tile0, int64_t tile1, int bmin)
 {
+    // levels bmin .. nbits - 1 (the leaf pass computes the levels below LEAF_T itself: their rows are never multiples of 64).
     // tiles [tile0, tile1) of 256 consecutive values of the coordinate z (a windowed layer needs the rows near its window only).
     // MIR = false: z = p, the candidate p belongs to the level-b row of the block [r - 2^b, r) iff bit b of z is CLEAR.
     // MIR = true (table with mir_w = w): z = p + w + 1, p belongs to the mirrored head rho = z with the bits <= b cleared
@@ -2133,7 +2156,7 @@ __global__ void __launch_bounds__(256) k_ra_cols(RATab T, const int32_t *__restr
     TC wv[4]; int32_t pv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { int64_t p = p0 + k; p = p < 0 ? 0 : p < n ? p : n; wv[k] = W[p]; pv[k] = pos[p]; }
-    for (int b = 0; b < T.nbits; b++) {
+    for (int b = bmin; b < T.nbits; b++) {
         if (b >= 8 && (bool)((Z0 >> b) & 1) != MIR) continue;       // (wave-uniform) no row of this level over the wave's columns
         // the lane's row of this level and its candidates among z0 .. z0 + 3:
         //   b = 0: two rows of one candidate each; b = 1: one row of two; b >= 2: all four
@@ -2511,8 +2534,8 @@ static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
         make_round(R, true, 0, sb + 1, n, 0, n, Wk.G, Wk.win_aoff);
         const unsigned wg = (unsigned)std::min<int64_t>(cdiv(acc, 4), 65536);
         for (int pass = 0; pass < (Wk.hyp ? 2 : 1); pass++) {
-            CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
-            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, A->N, n, w, A->col.p, A->next.p, Wk.w_hist.p); }
+            if (pass == 1 || A->N == 0) CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
+            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, w, A->pos32.p, A->prev.p, A->next.p, Wk.w_hist.p); }
             else if (A->m > 0) hipLaunchKernelGGL(k_win_hist_rows, dim3((unsigned)cdiv(A->m, 256)), dim3(256), 0, s, A->m, n, w, A->rfirst.p, A->rlast.p, Wk.w_hist.p);
             exclusive_scan_i32(Wk.w_hist.p, Wk.w_E.p, n + 1, Wk.scratch, s);
             if (pass == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_win_block_totals<true>), dim3(wg), dim3(256), 0, s, R, acc, A->pos32.p, A->next.p, Wk.w_tot.p);
@@ -2530,8 +2553,8 @@ static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
         Wk.leaf_anch.alloc((size_t)ng);
         if (Wk.hyp) Wk.leaf_anch2.alloc((size_t)ng);
         for (int pass = 0; pass < (Wk.hyp ? 2 : 1); pass++) {
-            CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
-            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(A->N, 256)), dim3(256), 0, s, A->N, n, w - 62, A->col.p, A->next.p, Wk.w_hist.p); }
+            if (pass == 1 || A->N == 0) CP_HIP(hipMemsetAsync(Wk.w_hist.p, 0, sizeof(int32_t) * (size_t)(n + 1), s));
+            if (pass == 0) { if (A->N > 0) hipLaunchKernelGGL(k_win_hist, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, s, n, w - 62, A->pos32.p, A->prev.p, A->next.p, Wk.w_hist.p); }
             else if (A->m > 0) hipLaunchKernelGGL(k_win_hist_rows, dim3((unsigned)cdiv(A->m, 256)), dim3(256), 0, s, A->m, n, w - 62, A->rfirst.p, A->rlast.p, Wk.w_hist.p);
             exclusive_scan_i32(Wk.w_hist.p, Wk.w_E.p, n + 1, Wk.scratch, s);
             hipLaunchKernelGGL(k_leaf_anchors, dim3((unsigned)cdiv(ng, 256)), dim3(256), 0, s, ng, n, pass == 0 ? A->pos.p : A->lpos.p, Wk.w_E.p,
@@ -2647,12 +2670,13 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             ProfScope ps(PROF_RA, s, 16.0 * (double)Wk.ra_ntile * LT);
             const bool colmajor = !(g_opt_dbg & 262144);       // (dbg 262144: the row-major kernel k_ra_layer)
             const unsigned cgrid = (unsigned)cdiv(cdiv(n, LT), 4);
+            const int ra_bmin = (leaf && !Wk.planes_full && !(g_opt_dbg & 33554432)) ? LEAF_T : 0;      // (dbg 33554432: all levels, as without the leaf pass)
             if (colmajor && hyp)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, (int64_t)0, cdiv(n, LT));
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, (int64_t)0, cdiv(n, LT), ra_bmin);
             else if (colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, false>), dim3(cgrid), dim3(256), 0, s, Wk.ra_tab, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p), (int64_t)0, cdiv(n, LT));
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p), (int64_t)0, cdiv(n, LT), ra_bmin);
             if (hyp) {
                 if (!colmajor)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.ra_ntile, 4)), dim3(256), 0, s, Wk.ra_tab, Wk.ra_ntile, Wk.ra_c.p, Wk.ra_c2.p,
@@ -2683,15 +2707,18 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             const int64_t tile0 = c_lo / LT, tile1 = cdiv(c_hi, LT);
             ProfScope ps(PROF_RA, s, 60.0 * (double)(tile1 - tile0) * LT);
             const unsigned cgrid = (unsigned)std::max<int64_t>(1, cdiv(tile1 - tile0, 4));
+            // (the standard heads below LEAF_T are rows inside a leaf group: the leaf pass computes them; the MIRRORED heads of those
+            //  levels include the multiples of 64 -- every row has a task in every plane -- and stay)
+            const int ra_bmin2 = (leaf && !Wk.planes_full && !(g_opt_dbg & 33554432)) ? LEAF_T : 0;
             if (hyp) {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, Wk.ra_c2.p, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, tile0, tile1);
+                                   Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.ra_part.p, tile0, tile1, ra_bmin2);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, true>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   Wk.ra_part.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p);
             } else {
                 auto *pa = reinterpret_cast<Best<TC, false> *>(Wk.ra_part.p);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, false>), dim3(cgrid), dim3(256), 0, s, T2, Wk.ra_c.p, (const int32_t *)nullptr, A->pos32.p, W, M, alpha,
-                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa, tile0, tile1);
+                                   Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pa, tile0, tile1, ra_bmin2);
                 if (nrow2 > 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_merge<TC, false>), dim3((unsigned)cdiv(nrow2, 4)), dim3(256), 0, s, T2, nrow2,
                                                   pa, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr);
             }
@@ -2718,7 +2745,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     const unsigned mgrid = (unsigned)std::max<int64_t>(1, cdiv(zt1 - zt0, 4));
                     if (hyp) {
                         if (mcols) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, true, true>), dim3(mgrid), dim3(256), 0, s, T3, Wk.mir_c.p, Wk.mir_c2.p, A->pos32.p, W, M, alpha,
-                                                      Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p, zt0, zt1);
+                                                      Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p, zt0, zt1, 0);
                         else
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, true>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p, Wk.mir_c2.p,
                                            A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.mir_part.p);
@@ -2727,7 +2754,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     } else {
                         auto *pm = reinterpret_cast<Best<TC, false> *>(Wk.mir_part.p);
                         if (mcols) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_cols<TC, false, true>), dim3(mgrid), dim3(256), 0, s, T3, Wk.mir_c.p, (const int32_t *)nullptr, A->pos32.p, W, M,
-                                                      alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm, zt0, zt1);
+                                                      alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm, zt0, zt1, 0);
                         else
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ra_layer<TC, false>), dim3((unsigned)cdiv(Wk.mir_ntile, 4)), dim3(256), 0, s, T3, Wk.mir_ntile, Wk.mir_c.p,
                                            (const int32_t *)nullptr, A->pos32.p, W, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr, pm);
