@@ -725,6 +725,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "prof_only")) { g_prof_only = (int)value; return CP_OK; }
     if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
+    if (!strcmp(name, "gap_nr")) { g_opt_gap_nr = value >= 2 ? 2 : 1; return CP_OK; }
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "leaf")) { g_opt_leaf = value; return CP_OK; }
     if (!strcmp(name, "poison")) { g_opt_poison = value; if (value) { g_poison_hits = 0; g_spec_redo = 0; } return CP_OK; }

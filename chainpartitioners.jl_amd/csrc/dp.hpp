@@ -51,6 +51,7 @@ int32_t run_plaid_dynamic(cp_csr_s *A, int64_t K, int32_t combine, int32_t order
 template <typename TC>
 bool pack_dynamic_scan(hipStream_t s, int64_t n, int64_t wmax, const TC *Ftab, TC *cst1, int64_t *spl1);
 
+extern int64_t g_opt_gap_nr;                      // 64-row chunks per wave of the gap finish (1 or 2)
 extern int64_t g_opt_gap_tau, g_opt_gap_min;   // gap passes in the rounds tau <= gap_tau (-1: none) for tasks of >= gap_min candidates
 extern int64_t g_opt_poison, g_poison_hits;    // poison mode (tests): see run_layer
 extern int64_t g_opt_leaf;                     // 1: the rounds tau < 6 of an unconstrained layer are one leaf pass (dp_leaf.inc)

@@ -25,7 +25,7 @@ int64_t g_opt_force_max = 1024;           // a round's flattened stage is replac
 int64_t g_opt_setup_bs = 1024;          // lanes per block of k_setup_short (a multiple of 64, at most 1024)
 int64_t g_opt_rpass_cap = 200;          // lane-private entries per row in k_rpass_small, per cent of the mean
 int64_t g_opt_nospec = 0, g_spec_redo = 0;
-int64_t g_opt_gap_tau = 6, g_opt_gap_min = 64;
+int64_t g_opt_gap_tau = 6, g_opt_gap_min = 64, g_opt_gap_nr = 2;
 int64_t g_opt_ra_cache = 1;
 int64_t g_opt_leaf = 1, g_opt_block_tables = 0;
 int64_t g_opt_poison = 0, g_poison_hits = 0;

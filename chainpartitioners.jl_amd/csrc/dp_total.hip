@@ -1096,12 +1096,14 @@ __device__ __forceinline__ int64_t rdl64(int64_t v, int src)
 }
 __device__ __forceinline__ double rdl64(double v, int src) { return __longlong_as_double((long long)rdl64((int64_t)__double_as_longlong(v), src)); }
 
-// the tiles [ka, kz) of a task (first tile k0, head B, L steps, row r) walked for the 64 rows of the wave: the winners so far
-// (bv, bp, bl, bl2) and the specials the rows count so far (cum, cum2) are carried in and out
-template <typename TC, bool HYP>
+// the tiles [ka, kz) of a task (first tile k0, head B, L steps, row r) walked for NR x 64 rows of the wave (lane l holds the rows
+// rr[0 .. NR-1], one per 64-row chunk: the tile records are fetched once for all of them): the winners so far (bv, bp, bl, bl2)
+// and the specials the rows count so far (cum, cum2) are carried in and out
+template <typename TC, bool HYP, int NR>
 __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevModel<TC> &M, TC alpha, int64_t ka, int64_t kz, int64_t k0,
-                                         int32_t B, int32_t L, int32_t r, int32_t posr, int32_t rr, int32_t rcmp, bool valid, int lane,
-                                         TC &bv, int32_t &bp, int32_t &bl, int32_t &bl2, int32_t &cum, int32_t &cum2)
+                                         int32_t B, int32_t L, int32_t r, int32_t posr, const int32_t (&rr)[NR], const int32_t (&rcmp)[NR],
+                                         const bool (&valid)[NR], int lane,
+                                         TC (&bv)[NR], int32_t (&bp)[NR], int32_t (&bl)[NR], int32_t (&bl2)[NR], int32_t (&cum)[NR], int32_t (&cum2)[NR])
 {
     const int64_t ps0 = C.tilePS[k0], ps20 = HYP ? C.tilePS2[k0] : 0;
     for (int64_t kb = ka; kb < kz; kb += 64) {
@@ -1141,20 +1143,26 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
                 Best<TC, HYP> d = c;
                 if (ns) { d.v = rdl64(c.v, sg); d.p = rdl(c.p, sg); d.nn = rdl(c.nn, sg); if (HYP) best_set_nl(d, rdl(best_nl(c), sg)); }
                 if (d.p >= 0) {
-                    int32_t lc = d.nn + base + cum, lc2 = HYP ? best_nl(d) + base2 + cum2 : 0;
-                    TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum), (int64_t)(base2 + cum2)));
-                    if (bp < 0 || v < bv) { bv = v; bp = d.p; bl = lc; bl2 = lc2; }
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        int32_t lc = d.nn + base + cum[u], lc2 = HYP ? best_nl(d) + base2 + cum2[u] : 0;
+                        TC v = cadd(d.v, dm_apply(M, (TC)0, (int64_t)0, (int64_t)0, (int64_t)(base + cum[u]), (int64_t)(base2 + cum2[u])));
+                        if (bp[u] < 0 || v < bv[u]) { bv[u] = v; bp[u] = d.p; bl[u] = lc; bl2[u] = lc2; }
+                    }
                 }
                 if (sg < ns) {                          // the candidates from here on have this special on their right
                     const int32_t s1 = rdl(sv, sg), val = s1 & 0x7fffffff;
                     const bool first_list = s1 >= 0;        // (two unconditional adds: an if / else here becomes ONE add through a selected address, i.e. scratch)
-                    cum += (first_list && val >= rcmp);
-                    cum2 += (!first_list && valid && val < rr);
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        cum[u] += (first_list && val >= rcmp[u]);
+                        cum2[u] += (!first_list && valid[u] && val < rr[u]);
+                    }
                 }
             }
             continue;
         }
-        // too many specials: every lane counts for its own row, entry by entry
+        // too many specials: every lane counts for its own rows, entry by entry
         const int head = k == k0 ? 1 : 0;
         const int32_t pf = B - (int32_t)(k - k0) * LT;
         int32_t tlk = L - (int32_t)(k - k0) * LT; tlk = (tlk < LT ? tlk : LT) - 1;
@@ -1170,7 +1178,9 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) { int32_t e = lane + 64 * j; wk[j] = e <= tlk ? C.W[pf - e] : (TC)0; }
-        int32_t run = 0, run2 = 0;
+        int32_t run[NR], run2[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) { run[u] = 0; run2[u] = 0; }
         int32_t wb = INT32_MAX, reg = 0, wb2 = INT32_MAX, reg2 = 0;
         for (int32_t e = 0; e <= tlk; e++) {
             const int32_t p = pf - e, e1 = e + 1;
@@ -1179,26 +1189,34 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
                 for (int32_t q = en - 1; q >= st; q--) {
                     if (q < wb || q - wb > 63) { wb = q - 63; reg = wb + lane >= 0 ? C.next[wb + lane] : 0; }
                     const int32_t x = __shfl(reg, q - wb);           // (every lane takes part: no short-circuit around a shuffle)
-                    run += (x >= rcmp);
+#pragma unroll
+                    for (int u = 0; u < NR; u++) run[u] += (x >= rcmp[u]);
                 }
                 if (HYP) {
                     const int32_t en2 = __shfl(CP_SEL5(pk2, e), e & 63), st2 = __shfl(CP_SEL5(pk2, e1), e1 & 63);
                     for (int32_t q = en2 - 1; q >= st2; q--) {
                         if (q < wb2 || q - wb2 > 63) { wb2 = q - 63; reg2 = wb2 + lane >= 0 ? C.flast[wb2 + lane] : 0; }
                         const int32_t x = __shfl(reg2, q - wb2);
-                        run2 += (valid && x < rr);
+#pragma unroll
+                        for (int u = 0; u < NR; u++) run2[u] += (valid[u] && x < rr[u]);
                     }
                 }
             }
             const TC wp = shfl64(e < 64 ? wk[0] : e < 128 ? wk[1] : e < 192 ? wk[2] : wk[3], e & 63);
-            int32_t lc = base + cum + run, lc2 = base2 + cum2 + run2;
-            TC v = cadd(wp, dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - st), (int64_t)lc, (int64_t)lc2));
-            if (bp < 0 || v < bv) { bv = v; bp = p; bl = lc; bl2 = lc2; }
+#pragma unroll
+            for (int u = 0; u < NR; u++) {
+                int32_t lc = base + cum[u] + run[u], lc2 = base2 + cum2[u] + run2[u];
+                TC v = cadd(wp, dm_apply(M, alpha, (int64_t)(r - p), (int64_t)(posr - st), (int64_t)lc, (int64_t)lc2));      // (the task's row: the rows' values differ by a row-only term)
+                if (bp[u] < 0 || v < bv[u]) { bv[u] = v; bp[u] = p; bl[u] = lc; bl2[u] = lc2; }
+            }
         }
 #undef CP_SEL5
-        // from here on the row also counts the specials of this tile it passed
-        cum += run - (int32_t)(C.tilePS[k + 1] - C.tilePS[k]);
-        if (HYP) cum2 += run2 - (int32_t)(C.tilePS2[k + 1] - C.tilePS2[k]);
+        // from here on the rows also count the specials of this tile they passed
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            cum[u] += run[u] - (int32_t)(C.tilePS[k + 1] - C.tilePS[k]);
+            if (HYP) cum2[u] += run2[u] - (int32_t)(C.tilePS2[k + 1] - C.tilePS2[k]);
+        }
     }
     }
 }
@@ -1225,8 +1243,11 @@ constexpr int GAPSEG = 16;      // tiles one wave walks; longer tasks are walked
 template <typename TC, bool HYP>
 struct GapSegRec { TC v; int32_t p, l, l2, cum, cum2, _pad; };
 
-template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCounts *__restrict__ rc, int64_t n,
+// NR: 64-row chunks per wave (a lane holds one row of each): the task's records -- descriptor, tile winners, segment lists -- are
+// fetched once for NR x 64 rows.  The kernel waits on memory three quarters of its time at four waves per SIMD (profiles/
+// r03_pmc_gap_finish.txt), i.e. it is bound by the number of (task, rows) items times the dependent loads of one item.
+template <typename TC, bool HYP, int NR>
+__global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, RoundCounts *__restrict__ rc, int64_t n,
                                                     const int64_t *__restrict__ toffs, GapCtx<TC, HYP> C,
                                                     const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ rlen,
                                                     const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
@@ -1235,13 +1256,14 @@ __global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCo
                                                     int2 *__restrict__ glist, int2 *__restrict__ gslot)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t nwork = (int64_t)rc->nown * nchunk, n1 = n + 1;
+    const int nitem = (nchunk + NR - 1) / NR;
+    const int64_t nwork = (int64_t)rc->nown * nitem, n1 = n + 1;
     for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
-        const int64_t t = w / nchunk;
-        const int ck = (int)(w - t * nchunk);
+        const int64_t t = w / nitem;
+        const int ck0 = (int)(w - t * nitem) * NR;
         const int64_t k0 = toffs[t], k1 = toffs[t + 1];
         if (k1 - k0 > GAPSEG) {                             // (wave-uniform) a long task: listed for k_gap_seg / k_gap_merge
-            if (ck == 0 && lane == 0) {
+            if (ck0 == 0 && lane == 0) {
                 int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
                 int idx = atomicAdd(&rc->n_glong, 1), slot0 = atomicAdd(&rc->n_gslots, nseg);
                 glist[idx] = make_int2((int)t, slot0);
@@ -1252,20 +1274,35 @@ __global__ void __launch_bounds__(256) k_gap_finish(int tau, int nchunk, RoundCo
         const int4 td = tdesc[t];                           // {B, anchor + right part of the task's own row, row r, pos[r]}
         const int b = tb[t];
         const int32_t B = td.x, r = td.z, posr = td.w, L = rlen[t];
-        const GapRows g = gap_rows(tau, ck, r, b, n, lane);
-        if (g.none) continue;
+        GapRows g[NR];
+        int32_t rr[NR], rcmp[NR]; bool valid[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) { g[u] = gap_rows(tau, ck0 + u, r, b, n, lane); rr[u] = g[u].rr; rcmp[u] = g[u].rcmp; valid[u] = g[u].valid; }
+        if (g[0].none) continue;
         // right parts of the rows and the anchor (counts at (B, rL))
-        const int32_t Rr = gap_right_counts<false>(C.pos, prev, g.rL, ck, B, (int32_t)n, lane);
-        const int32_t Rr2 = HYP ? gap_right_counts<true>(lpos, lfirst, g.rL, ck, B, (int32_t)n, lane) : 0;
-        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)g.rL);
+        int32_t Rr[NR], Rr2[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            Rr[u] = 0; Rr2[u] = 0;
+            if (u == 0 || !g[u].none) {                     // (wave-uniform)
+                Rr[u] = gap_right_counts<false>(C.pos, prev, g[0].rL, ck0 + u, B, (int32_t)n, lane);
+                if (HYP) Rr2[u] = gap_right_counts<true>(lpos, lfirst, g[0].rL, ck0 + u, B, (int32_t)n, lane);
+            }
+        }
+        const int64_t rwL = (int64_t)b * n1 + PR((int64_t)g[0].rL);
         const int32_t anchor = nnopt[rwL], anchor2 = HYP ? nlopt[rwL] : 0;
-        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
-        gap_walk<TC, HYP>(C, M, alpha, k0, k1, k0, B, L, r, posr, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
-        if (g.valid) {
-            int64_t rw = (int64_t)b * n1 + PR((int64_t)g.rr);
-            opt[rw] = bp; nnopt[rw] = anchor + Rr + bl;
-            if (HYP) nlopt[rw] = anchor2 + Rr2 + bl2;
-            fin[rw] = 1;
+        TC bv[NR]; int32_t bp[NR], bl[NR], bl2[NR], cum[NR], cum2[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) { bv[u] = (TC)0; bp[u] = -1; bl[u] = 0; bl2[u] = 0; cum[u] = 0; cum2[u] = 0; }
+        gap_walk<TC, HYP, NR>(C, M, alpha, k0, k1, k0, B, L, r, posr, rr, rcmp, valid, lane, bv, bp, bl, bl2, cum, cum2);
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            if (valid[u]) {
+                int64_t rw = (int64_t)b * n1 + PR((int64_t)rr[u]);
+                opt[rw] = bp[u]; nnopt[rw] = anchor + Rr[u] + bl[u];
+                if (HYP) nlopt[rw] = anchor2 + Rr2[u] + bl2[u];
+                fin[rw] = 1;
+            }
         }
     }
 }
@@ -1289,10 +1326,11 @@ __global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, const Roun
         const int4 td = tdesc[t];
         const GapRows g = gap_rows(tau, ck, td.z, tb[t], n, lane);
         if (g.none) continue;
-        TC bv = (TC)0; int32_t bp = -1, bl = 0, bl2 = 0, cum = 0, cum2 = 0;
+        TC bv[1] = {(TC)0}; int32_t bp[1] = {-1}, bl[1] = {0}, bl2[1] = {0}, cum[1] = {0}, cum2[1] = {0};
+        const int32_t rr1[1] = {g.rr}, rcmp1[1] = {g.rcmp}; const bool valid1[1] = {g.valid};
         const int64_t ka = k0 + (int64_t)sg * GAPSEG, kz = ka + GAPSEG < k1 ? ka + GAPSEG : k1;
-        gap_walk<TC, HYP>(C, M, alpha, ka, kz, k0, td.x, rlen[t], td.z, td.w, g.rr, g.rcmp, g.valid, lane, bv, bp, bl, bl2, cum, cum2);
-        GapSegRec<TC, HYP> rec; rec.v = bv; rec.p = bp; rec.l = bl; rec.l2 = bl2; rec.cum = cum; rec.cum2 = cum2; rec._pad = 0;
+        gap_walk<TC, HYP, 1>(C, M, alpha, ka, kz, k0, td.x, rlen[t], td.z, td.w, rr1, rcmp1, valid1, lane, bv, bp, bl, bl2, cum, cum2);
+        GapSegRec<TC, HYP> rec; rec.v = bv[0]; rec.p = bp[0]; rec.l = bl[0]; rec.l2 = bl2[0]; rec.cum = cum[0]; rec.cum2 = cum2[0]; rec._pad = 0;
         gseg[(slot * nchunk + ck) * 64 + lane] = rec;
     }
 }
@@ -2889,13 +2927,18 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 const size_t ncap = Wk.o_rec.n / GAPSEG + 2;
                 Wk.g_list.ensure(ncap); Wk.g_slot.ensure(2 * ncap);
                 Wk.g_seg.ensure((2 * ncap) * (size_t)nchunk * 64 * sizeof(GapSegRec<TC, true>));
-                unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * nchunk, 4), 16384);
+                const int gnr = (g_opt_gap_nr >= 2 && nchunk >= 2) ? 2 : 1;       // 64-row chunks per wave of k_gap_finish
+                unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * cdiv((int64_t)nchunk, gnr), 4), 16384);
                 unsigned gs_grid = (unsigned)std::min<int64_t>(cdiv((int64_t)(2 * ncap) * nchunk, 4), 8192);
                 unsigned gm = (unsigned)std::min<int64_t>(cdiv((int64_t)ncap * nchunk, 4), 4096);
                 if (hyp) {
                     GapCtx<TC, true> C{Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, Wk.o_spec.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->fpos32.p, A->flast.p, W};
                     auto *gs = reinterpret_cast<GapSegRec<TC, true> *>(Wk.g_seg.p);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                    if (gnr == 2)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                    else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
@@ -2905,7 +2948,12 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     GapCtx<TC, false> C{reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p), Wk.o_spv.p,
                                         Wk.o_spec.p, Wk.o_tilePS.p, nullptr, A->pos32.p, A->next.p, nullptr, nullptr, W};
                     auto *gs = reinterpret_cast<GapSegRec<TC, false> *>(Wk.g_seg.p);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                    if (gnr == 2)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
+                                       Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
+                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                    else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
                                        Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,

@@ -25,9 +25,11 @@ MODELS = [cp.AffineConnectivityModel(0, 0, 0, 1), cp.AffineConnectivityModel(1, 
 OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"ra_cache": 0}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
            {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"force_max": 1000000}, {"dbg": 262144}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048},
            # the rounds tau < 6 as divide-and-conquer rounds (the path before the leaf pass, csrc/dp_leaf.inc), alone and with the gap passes reaching down
-           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}, {"leaf": 0, "short_t": 0, "short_e": 0}]
+           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}, {"leaf": 0, "short_t": 0, "short_e": 0},
+           # the gap finish with one 64-row chunk per wave (default: two), the round-A levels the leaf pass recomputes kept (dbg 33554432)
+           {"gap_nr": 1}, {"gap_nr": 1, "gap_tau": 8, "gap_min": 8}, {"dbg": 33554432}]
 DEFAULTS = {"nospec": 0, "gap_tau": 6, "gap_min": 64, "ra_cache": 1, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024,
-            "short_t": 8, "short_e": 64, "own_min": 64, "leaf": 1}
+            "short_t": 8, "short_e": 64, "own_min": 64, "leaf": 1, "gap_nr": 2}
 
 
 def w_rows(rng, n, scale, dt):

@@ -62,8 +62,8 @@ def test_constrained_tables_bit_exact(hip, orc, mi):
 OPTIONS = [{}, {"nospec": 1}, {"gap_tau": -1}, {"gap_tau": 8, "gap_min": 8}, {"dbg": 64}, {"dbg": 512, "gap_tau": 7, "gap_min": 8},
            {"short_t": 0, "short_e": 0}, {"own_min": 1000}, {"rpass_small_tau": 6}, {"rpass_ch": 16}, {"rpass_small_tau": -1, "rpass_ch": 16}, {"rpass_cap": 1}, {"dbg": 524288}, {"dbg": 1048576}, {"dbg": 2097152}, {"dbg": 8388608}, {"ra_cache": 0}, {"force_max": 1000000}, {"dbg": 16384}, {"setup_bs": 128}, {"rpass_small_tau": 9, "rpass_cap": 30}, {"dbg": 1024}, {"dbg": 2048},
            # without the leaf pass (csrc/dp_leaf.inc): the rounds tau < 6 as divide-and-conquer rounds
-           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}]
-DEFAULTS = {"leaf": 1, "ra_cache": 1, "nospec": 0, "gap_tau": 6, "gap_min": 64, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "short_t": 8, "short_e": 64, "own_min": 64}
+           {"leaf": 0}, {"leaf": 0, "gap_tau": 8, "gap_min": 8}, {"gap_nr": 1}, {"gap_nr": 1, "gap_tau": 8, "gap_min": 8}, {"dbg": 33554432}]
+DEFAULTS = {"leaf": 1, "ra_cache": 1, "nospec": 0, "gap_tau": 6, "gap_min": 64, "dbg": 0, "rpass_small_tau": 4, "rpass_ch": 256, "rpass_cap": 200, "force_max": 1024, "setup_bs": 1024, "short_t": 8, "short_e": 64, "own_min": 64, "gap_nr": 2}
 
 
 @pytest.mark.parametrize("oi", range(len(OPTIONS)))
