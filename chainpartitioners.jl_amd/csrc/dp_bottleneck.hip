@@ -145,7 +145,7 @@ __device__ __forceinline__ bool bn_pred(const BnCtx<TC> &C, int64_t p, int64_t r
 template <typename TC>
 __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk, int stride, int coarse,
                                                    int32_t *__restrict__ c0, int32_t *__restrict__ nn0, int32_t *__restrict__ nl0,
-                                                   const int32_t *__restrict__ hint, const int32_t *__restrict__ hint2, int32_t slack)
+                                                   const int32_t *__restrict__ hint, const int32_t *__restrict__ hint2, int32_t slack, int64_t rmin)
 {
     // slack >= 0 (the wave-per-run walks): ANY column at or left of the crossing will do as a start -- the walk searches forward
     // from it -- so the gallop starts with steps of `slack` columns and the bisection stops at a bracket of `slack` columns: a
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int
     // chunks t = 0, stride, 2 stride, ...; coarse != 0: those that are multiples of `coarse` are known already and bracket the rest
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
     if (t >= nchunk || (coarse && t % coarse == 0)) return;
-    const int64_t r = rlo + t * CH;
+    const int64_t r = rlo + t * CH > rmin ? rlo + t * CH : rmin;      // (rmin > rlo: a tiling aligned to multiples of CH whose first chunk starts inside it)
     const int64_t lo0 = bn_plo(C, r), phi = bn_phi(C, r);   // the row's candidates (the whole range [0, r] without a window)
     int64_t lo = lo0, hi = phi + 1;                         // the answer lies in [lo, hi]; pred counts as true at hi (phi + 1: "no crossing")
     if (lo > hi) lo = hi;
@@ -477,7 +477,8 @@ constexpr int BN_SPEC = 256;      // specials of a window kept in LDS per list; 
 template <bool HYP>
 __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t rlo, int64_t rhi, int64_t CH, int64_t nchunk,
                                                      const int32_t *__restrict__ c0, const int32_t *__restrict__ nn0, const int32_t *__restrict__ nl0,
-                                                     const int32_t *__restrict__ runend, int64_t *__restrict__ cst, int32_t *__restrict__ ptr, int32_t *__restrict__ hint_out)
+                                                     const int32_t *__restrict__ runend, int64_t *__restrict__ cst, int32_t *__restrict__ ptr, int32_t *__restrict__ hint_out,
+                                                     int64_t rmin)
 {
     typedef int64_t TC;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -490,8 +491,8 @@ __global__ void __launch_bounds__(256) k_bn_walk_vec(BnCtx<int64_t> C, int64_t r
     const TC kV = C.M.p[CP_P_VERTEX], kP = C.M.p[CP_P_PIN];
     const TC kN = C.M.kind == CP_MODEL_CONNECTIVITY ? C.M.p[CP_P_NET] : (C.M.kind == CP_MODEL_HYPEREDGE_CUT ? C.M.p[CP_P_CUT_NET] : (TC)0);
     const TC kL = C.M.kind == CP_MODEL_HYPEREDGE_CUT ? csub(C.M.p[CP_P_SELF_NET], C.M.p[CP_P_CUT_NET]) : (TC)0;
-    const int32_t r_begin = (int32_t)(rlo + t * CH);
-    int32_t r_end = (int32_t)(r_begin + CH - 1);
+    const int32_t r_begin = (int32_t)(rlo + t * CH > rmin ? rlo + t * CH : rmin);
+    int32_t r_end = (int32_t)(rlo + (t + 1) * CH - 1);
     if (r_end > rhi) r_end = (int32_t)rhi;
     int32_t cs = c0[t], nn_a = nn0[t], nl_a = nl0[t];
     for (int32_t a = r_begin;;) {
@@ -708,6 +709,7 @@ struct BnWork {
     WaveletHost net, self;
     DBuf<int32_t> runend, blk, c0, nn0, nl0, hint, hint2;
     int64_t hint_rlo = -1, hint_nchunk = -1, hint_ch = -1;      // the tiling the hints belong to (-1: none)
+    int hint_limited = -1;                                      // ... 1: a weight-constrained layer (hints per absolute chunk), 0: a plain one
     int hint_layers = 0;                                        // how many consecutive layers of that tiling the hints cover (hint: last, hint2: the one before)
 };
 
@@ -754,16 +756,30 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     const int64_t nblk = cdiv(n1, 1024);
     B->runend.ensure((size_t)n1); B->blk.ensure((size_t)nblk + 1);
     const bool wave = g_opt_bn_wave != 0;
-    const int64_t CH = wave ? std::max<int64_t>(2, g_opt_bn_run) : std::max<int64_t>(1, g_opt_bn_chunk), nchunk = cdiv(rhi - rlo + 1, CH);
+    const int64_t CH = wave ? std::max<int64_t>(2, g_opt_bn_run) : std::max<int64_t>(1, g_opt_bn_chunk);
+    // A weight-constrained layer's row window moves from layer to layer: its chunks are aligned to multiples of CH (the first one
+    // starts inside its chunk, at rmin) and the hints are kept per ABSOLUTE chunk, so a row's crossing in the previous layer still
+    // guides its start (the windows of consecutive layers overlap almost entirely).  Any hint is safe: it only chooses where the
+    // search starts.
+    const int64_t rmin = rlo;
+    if (limited) rlo = (rlo / CH) * CH;
+    const int64_t tbase = limited ? rlo / CH : 0;
+    const int64_t nchunk = cdiv(rhi - rlo + 1, CH);
     B->c0.ensure((size_t)nchunk); B->nn0.ensure((size_t)nchunk); B->nl0.ensure((size_t)nchunk);
     ProfScope ps(PROF_BRUTE, s, 8.0 * (double)A->N + 24.0 * (double)(rhi - rlo + 1));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_run1<TC>), dim3((unsigned)nblk), dim3(1024), 0, s, n1, W, B->runend.p, B->blk.p);
     hipLaunchKernelGGL(k_bn_run2, dim3(1), dim3(1024), 0, s, nblk, B->blk.p);
     hipLaunchKernelGGL(k_bn_run3, dim3((unsigned)nblk), dim3(1024), 0, s, n1, nblk, B->runend.p, B->blk.p);
-    // (width-constrained layers move their row window from layer to layer: the hints are per chunk of ONE tiling, so they start afresh)
-    const bool hinted = B->hint_nchunk == nchunk && B->hint_rlo == rlo && B->hint_ch == CH && nchunk > 1;
+    const bool hinted = B->hint_ch == CH && nchunk > 1 && B->hint_limited == (limited ? 1 : 0) &&
+                        (limited ? B->hint_layers >= 1 : (B->hint_nchunk == nchunk && B->hint_rlo == rlo));
     if (!hinted) B->hint_layers = 0;
-    B->hint.ensure((size_t)nchunk); B->hint2.ensure((size_t)nchunk);
+    {
+        const size_t need = (size_t)std::max<int64_t>(nchunk, n1 / CH + 2);
+        if (B->hint.n < need || B->hint2.n < need) {
+            B->hint.ensure(need); B->hint2.ensure(need);
+            CP_HIP(hipMemsetAsync(B->hint.p, 0, B->hint.bytes(), s)); CP_HIP(hipMemsetAsync(B->hint2.p, 0, B->hint2.bytes(), s));
+        }
+    }
     // every 64th chunk from the previous layer's hint, the rest bracketed by those.  Tried, config 3 matrix, K = 64 (302 ms as is):
     //  - a level of every 8th chunk in between: 6 probes of the counter for most chunks instead of 9, but a third chain of
     //    dependent probes: 318 ms;
@@ -772,31 +788,31 @@ void dp_bottleneck_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC 
     //    (1.58 ms per layer against 0.9 ms);
     //  - the fine starts as a 4-ary search, three interleaved descents per step: 1.0 ms against 0.9 ms -- 1.25 M lanes are bound by
     //    the number of line requests, not by the length of the chain.
-    const int32_t *h1 = hinted ? B->hint.p : (const int32_t *)nullptr;
-    const int32_t *h2 = hinted && B->hint_layers >= 2 && !(g_opt_dbg & 4194304) ? B->hint2.p : (const int32_t *)nullptr;
+    const int32_t *h1 = hinted ? B->hint.p + tbase : (const int32_t *)nullptr;
+    const int32_t *h2 = hinted && B->hint_layers >= 2 && !(g_opt_dbg & 4194304) ? B->hint2.p + tbase : (const int32_t *)nullptr;
     if (hinted && wave && !(g_opt_dbg & 33554432)) {
         // the wave-per-run walks need one start per few hundred rows, and any column left of the crossing will do: the crossing of
         // the same row in the previous layer (continued by that layer's move) minus a slack, one confirming probe
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, 0, B->c0.p, B->nn0.p, B->nl0.p, h1, h2,
-                           (int32_t)g_opt_bn_slack);
+                           (int32_t)g_opt_bn_slack, rmin);
     } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(cdiv(nchunk, 64), 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 64, 0, B->c0.p, B->nn0.p,
-                       B->nl0.p, h1, h2, -1);
+                       B->nl0.p, h1, h2, -1, rmin);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_starts<TC>), dim3((unsigned)cdiv(nchunk, 256)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, 1, 64, B->c0.p, B->nn0.p, B->nl0.p,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, -1);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, -1, rmin);
     }
     std::swap(B->hint.p, B->hint2.p); std::swap(B->hint.n, B->hint2.n);      // (hint2 <- the previous layer's crossings)
     if (!wave) CP_HIP(hipMemcpyAsync(B->hint.p, B->c0.p, sizeof(int32_t) * (size_t)nchunk, hipMemcpyDeviceToDevice, s));      // (the wave walks store their first crossings themselves)
     B->hint_layers++;
-    B->hint_nchunk = nchunk; B->hint_rlo = rlo; B->hint_ch = CH;
+    B->hint_nchunk = nchunk; B->hint_rlo = rlo; B->hint_ch = CH; B->hint_limited = limited ? 1 : 0;
     if (wave && g_opt_bn_wave >= 2 && CostTraits<TC>::is_int) {
         // Int64 costs: the crossings by binary search over windows of 64 columns
         const BnCtx<int64_t> &Ci = reinterpret_cast<const BnCtx<int64_t> &>(C);
         int64_t *co = reinterpret_cast<int64_t *>(cst_out);
         if (hyp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk_vec<true>), dim3((unsigned)cdiv(nchunk, 4)), dim3(256), 0, s, Ci, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
-                                    B->runend.p, co, ptr_out, B->hint.p);
+                                    B->runend.p, co, ptr_out, B->hint.p + tbase, rmin);
         else     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk_vec<false>), dim3((unsigned)cdiv(nchunk, 4)), dim3(256), 0, s, Ci, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
-                                    B->runend.p, co, ptr_out, B->hint.p);
+                                    B->runend.p, co, ptr_out, B->hint.p + tbase, rmin);
     } else if (wave && hyp)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bn_walk64<TC, true>), dim3((unsigned)cdiv(nchunk, 4)), dim3(256), 0, s, C, rlo, rhi, CH, nchunk, B->c0.p, B->nn0.p, B->nl0.p,
                            B->runend.p, cst_out, ptr_out, B->hint.p);

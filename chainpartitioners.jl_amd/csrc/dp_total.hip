@@ -99,6 +99,7 @@ struct RoundDesc {
     // at the block start -- which every round would otherwise re-scan (n is not a power of two: ~n steps per round)
     int32_t nlast, last_b[31];
     int32_t skip_std, skip_mir; // windowed round A: the standard / mirrored heads (bit b of the row set / clear, b < s) come from the cached counts
+    int32_t fin_stamp;          // a cell of the `fin` plane is set iff it holds this layer's stamp (1 .. 255: the plane is cleared every 255 layers, not every layer)
 };
 
 // Per-round counters, on the device (one record per round, kept for the whole layer).  Kernels read their loop bounds from
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) k_last_row_counts(RoundDesc R, const int3
     if (threadIdx.x < 64) s_acc[threadIdx.x] = 0;
     __syncthreads();
     const int64_t n = R.n, n1 = n + 1;
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)R.nlast) fin[(int64_t)R.last_b[threadIdx.x] * n1 + prow(n, n)] = 1;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)R.nlast) fin[(int64_t)R.last_b[threadIdx.x] * n1 + prow(n, n)] = (uint8_t)R.fin_stamp;
     for (int pass = 0; pass < (lpos ? 2 : 1); pass++) {
         const int32_t *cp = pass ? lpos : pos, *arr = pass ? lfirst : prev;
         for (int i = 0; i < R.nlast; i++) {                 // (the ranges are nested; together at most 2 N entries)
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(1024) k_setup_short(RoundDesc R, int32_t *__re
             }
             // (rows of a tau round have ctz == tau: their plane slot needs no bit search)
             // finished by a gap pass of an earlier round?  (the flag is looked at AFTER the gathers below are on their way: one memory latency less)
-            if (fin) finb = fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))];
+            if (fin) finb = fin[(int64_t)b * (R.n + 1) + (R.n - (R.n >> R.tau)) + (r >> (R.tau + 1))] == (uint8_t)R.fin_stamp;
         }
     }
     if (live && R.G.win) {
@@ -1253,7 +1254,7 @@ __global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, Roun
                                                     const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
                                                     DevModel<TC> M, TC alpha,
                                                     int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin,
-                                                    int2 *__restrict__ glist, int2 *__restrict__ gslot)
+                                                    int2 *__restrict__ glist, int2 *__restrict__ gslot, int fin_stamp)
 {
     const int lane = threadIdx.x & 63;
     const int nitem = (nchunk + NR - 1) / NR;
@@ -1301,7 +1302,7 @@ __global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, Roun
                 int64_t rw = (int64_t)b * n1 + PR((int64_t)rr[u]);
                 opt[rw] = bp[u]; nnopt[rw] = anchor + Rr[u] + bl[u];
                 if (HYP) nlopt[rw] = anchor2 + Rr2[u] + bl2[u];
-                fin[rw] = 1;
+                fin[rw] = (uint8_t)fin_stamp;
             }
         }
     }
@@ -1343,7 +1344,7 @@ __global__ void __launch_bounds__(256) k_gap_merge(int tau, int nchunk, const Ro
                                                    const int32_t *__restrict__ pos, const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos,
                                                    const int32_t *__restrict__ lfirst, DevModel<TC> M, const int2 *__restrict__ glist,
                                                    const GapSegRec<TC, HYP> *__restrict__ gseg,
-                                                   int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin)
+                                                   int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin, int fin_stamp)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nwork = (int64_t)rc->n_glong * nchunk, n1 = n + 1;
@@ -1383,7 +1384,7 @@ __global__ void __launch_bounds__(256) k_gap_merge(int tau, int nchunk, const Ro
             int64_t rw = (int64_t)b * n1 + PR((int64_t)g.rr);
             opt[rw] = bp; nnopt[rw] = anchor + Rr + bl;
             if (HYP) nlopt[rw] = anchor2 + Rr2 + bl2;
-            fin[rw] = 1;
+            fin[rw] = (uint8_t)fin_stamp;
         }
     }
 }
@@ -2346,6 +2347,7 @@ struct LayerWork {
     DBuf<char> g_seg;                                   // their segment records (GapSegRec)
     DBuf<int32_t> last_s0;                              // anchors of the last row's round-A tasks ([b], [32 + b])
     DBuf<uint8_t> o_spec, fin;                          // gap passes: flagged tiles; rows already final (per plane slot)
+    int fin_stamp = 255;                                // ... iff the cell holds the current layer's stamp (run_layer; 255: cleared before the next layer)
     DBuf<int64_t> o_toffs, o_tilePS, o_tilePS2;
     DBuf<Best<TC, true>> o_part;
     int64_t max_tasks = 0;
@@ -2687,7 +2689,8 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
     // (s >= 6) and no per-block table is asked for
     const bool leaf = g_opt_leaf && (!G.win || (G.s >= LEAF_T && !g_opt_block_tables && Wk.leaf_anch.p));
     Wk.planes_full = !leaf || g_opt_block_tables;
-    CP_HIP(hipMemsetAsync(Wk.fin.p, 0, Wk.fin.bytes(), s));
+    // `fin` flags hold the layer's stamp: no 240 MB clear per layer (every attempt of a layer -- a redo included -- takes a new stamp)
+    if (++Wk.fin_stamp > 255 || Wk.fin_stamp <= 0) { CP_HIP(hipMemsetAsync(Wk.fin.p, 0, Wk.fin.bytes(), s)); Wk.fin_stamp = 1; }
     std::vector<RoundCounts> used((size_t)NR);          // what the host sized each round with
     memset(used.data(), 0, sizeof(RoundCounts) * (size_t)NR);
     struct Patch { size_t idx; int rd; int kind; };
@@ -2700,6 +2703,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
         RoundDesc R;
         if (rd == 0) make_round(R, true, 0, nbits, n, rlo, rhi, G, Wk.win_aoff);
         else make_round(R, false, nbits - rd, nbits, n, rlo, rhi, G, Wk.win_aoff);
+        R.fin_stamp = Wk.fin_stamp;
         if (leaf && !R.isA && R.tau < LEAF_T) continue;
         if (rd == 0 && g_opt_ra_cache && rlo <= 1 && rhi >= n && n >= 1 && !G.win) {
             // a full layer: round A of the rows' lowest blocks from the cached counts; what is left of round A below is the
@@ -2896,7 +2900,7 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 CP_HIP(hipMemsetAsync(Wk.o_rec.p, pat, Wk.o_rec.bytes(), s));
                 if (hyp) CP_HIP(hipMemsetAsync(Wk.o_tileS2.p, pat, Wk.o_tileS2.bytes(), s));
             }
-            hipLaunchKernelGGL(k_own_map, dim3((unsigned)cdiv(gNT, 256)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p,
+            hipLaunchKernelGGL(k_own_map, dim3((unsigned)std::min<int64_t>(cdiv(gNT, 256), 8192)), dim3(256), 0, s, rc, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_rlen.p, Wk.o_rec.p, Wk.o_task.p,
                                Wk.o_tb.p, gap ? Wk.o_hi.p : (int32_t *)nullptr, R.tau, n);
             {
                 ProfScope ps(gap ? PROF_GAPSTREAM : PROF_OWN, s, (double)P.own_steps * step_bytes);      // same bytes per step as dp_lpass
@@ -2936,14 +2940,14 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     auto *gs = reinterpret_cast<GapSegRec<TC, true> *>(Wk.g_seg.p);
                     if (gnr == 2)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
                     else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, true>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       A->pos32.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p);
+                                       A->pos32.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.fin_stamp);
                 } else {
                     GapCtx<TC, false> C{reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p), Wk.o_spv.p,
                                         Wk.o_spec.p, Wk.o_tilePS.p, nullptr, A->pos32.p, A->next.p, nullptr, nullptr, W};
@@ -2951,16 +2955,16 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                     if (gnr == 2)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
                     else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p);
+                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
                                        Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, false>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
                                        A->pos32.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p,
-                                       (int32_t *)nullptr, Wk.fin.p);
+                                       (int32_t *)nullptr, Wk.fin.p, Wk.fin_stamp);
                 }
             } else {
                 ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
@@ -3068,11 +3072,11 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
             // group flags the layer (err) and skips the plane.
             const int32_t lcap = (gaps && g_opt_gap_tau >= LEAF_T) ? (int32_t)std::max<int64_t>(g_opt_gap_min, 2) : INT32_MAX;
             LeafArgs<TC, false> L0{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
-                                   nullptr, nullptr, nullptr, nullptr, nullptr, Wk.opt.p, Wk.nnopt.p, nullptr, Wk.fin.p, W, M, alpha, cst_out, ptr_out,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, Wk.opt.p, Wk.nnopt.p, nullptr, Wk.fin.p, Wk.fin_stamp, W, M, alpha, cst_out, ptr_out,
                                    G, Wk.leaf_anch.p, nullptr, lcap, &Wk.rc.p->err, pzp};
             if (hyp) {
                 LeafArgs<TC, true> L1{n, g0, g1 - g0 + 1, c0, c1, nbits, (int32_t)(g_opt_block_tables != 0), A->pos32.p, A->prev.p, A->next.p, A->col.p,
-                                      A->fpos32.p, A->flast.p, A->ffirst.p, A->lpos32.p, A->lfirst.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, W, M, alpha,
+                                      A->fpos32.p, A->flast.p, A->ffirst.p, A->lpos32.p, A->lfirst.p, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.fin_stamp, W, M, alpha,
                                       cst_out, ptr_out, G, Wk.leaf_anch.p, Wk.leaf_anch2.p, lcap, &Wk.rc.p->err, pzp};
                 const unsigned lg = (unsigned)cdiv(L1.ngroups, LeafWPB<true>::v);
                 if (need <= 18) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf<TC, true, 18>), dim3(lg), dim3(64 * LeafWPB<true>::v), 0, s, L1);
@@ -3191,7 +3195,7 @@ void dp_total_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W, T
         Wk.o_tdesc.alloc(mo); Wk.o_tb.alloc(mo); Wk.o_rlen.alloc(mo); Wk.o_ntl.alloc(mo); Wk.o_toffs.alloc(mo + 1); Wk.o_wide.alloc(mo);
         if (hyp) Wk.o_tS0l.alloc(mo);
         Wk.rc.alloc((size_t)NBMAX + 2);
-        Wk.fin.alloc(plane); Wk.last_s0.alloc(64);
+        Wk.fin.alloc(plane); Wk.last_s0.alloc(64); Wk.fin_stamp = 255;      // (fresh memory: the first layer clears it)
         Wk.n = n;
     }
     // geometry of this call: wwin > 0: candidates of row r are max(0, r - wwin) <= p <= r

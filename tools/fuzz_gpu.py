@@ -77,6 +77,8 @@ while time.time() - t0 < budget:
                   cp.ConstrainedCost(f, cp.AffineWorkModel(0.25 * a0, 0.5 * c, 0.0), 0.25 * a0 + 0.5 * c * w + 0.1) if wk == 2 else
                   cp.ConstrainedCost(f, cp.AffineWorkModel(a0, c - 1, 1), a0 + (c - 1) * w + int(w * max(A.nnz, 1) / max(A.n, 1)) + int(rng.integers(0, 5))))
             for meth in (cp.DynamicTotalSplitter(fc), cp.DynamicTotalChunker(fc), cp.DynamicBottleneckSplitter(fc), cp.DynamicBottleneckChunker(fc)):
+                if wk == 3 and A.n > 600 and meth.combine == 0:
+                    continue                       # (total cost under a pin weight: the one-wave literal kernel, 40 s at n = 6000)
                 if meth.order == 1 and getattr(f, "alpha_k", None) is not None:
                     continue
                 got = cp.partition_stripe(A, K, meth, backend=hip)
