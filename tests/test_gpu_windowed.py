@@ -185,3 +185,20 @@ def test_width_weights_take_the_windowed_path(hip, orc):
     A = suitesparse_shaped(400, 5, 2)
     f = cp.ConstrainedCost(net, cp.AffineWorkModel(0, 1, 1), 700)
     assert cp.partition_stripe(A, 4, cp.DynamicTotalSplitter(f), backend=hip) == cp.partition_stripe(A, 4, cp.DynamicTotalSplitter(f), backend=orc)
+
+
+def test_many_layers_on_one_handle(hip, orc):
+    """K = 300 layers through one handle: the per-layer state that is NOT re-initialised every layer (the `fin` plane holds a layer
+    stamp that wraps after 255 layers, csrc/dp_total.hip run_layer) must not leak from one layer into another"""
+    A = suitesparse_shaped(2000, 8, 21)
+    for mdl in (MODELS[1], MODELS[4]):
+        for (K, w) in [(300, 600), (520, 130)]:
+            f = cp.ConstrainedCost(mdl, cp.VertexCount(), w)
+            got = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=hip)
+            want = cp.partition_stripe(A, K, cp.DynamicTotalSplitter(f), backend=orc)
+            assert got == want, (K, w)
+    # the unconstrained layers too, with a gap-heavy previous row every time (tables compared cell by cell)
+    mm = MODELS[1].marshal()
+    rc1, p1, c1 = hip.dynamic_tables(A, 300, 0, mm, None)
+    rc2, p2, c2 = orc.dynamic_tables(A, 300, 0, mm, None)
+    assert rc1 == 0 and rc2 == 0 and np.array_equal(p1, p2) and np.array_equal(c1, c2)
