@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing experiment for the leaf pass: k_leaf's time per layer with parts of it compiled out (library builds with -DCP_LEAF_SKIP=mask,
 selected through CP_LIB_PATH; the results of such a build are WRONG -- only the `dp_leaf` profile slot is read).
-usage: CP_LIB_PATH=build/ab/libchainpart_skipN.so python tools/leaf_parts.py [constrained]"""
+usage: CP_LIB_PATH=build/ab/libchainpart_skipN.so python tools/leaf_parts.py [constrained|plain] [profile slots, comma separated]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,4 +24,5 @@ for rep in range(2):
     hip.partition_dynamic(h, K, 0, 0, mdl, None, wm, w, float(w), spl)
     torch.cuda.synchronize()
     p = hip.prof_get()
-print(os.environ.get("CP_LIB_PATH", "base"), "dp_leaf ms per layer: %.3f (launches %d)" % (p["dp_leaf"]["ms"] / max(p["dp_leaf"]["launches"], 1), p["dp_leaf"]["launches"]))
+slots = sys.argv[2].split(",") if len(sys.argv) > 2 else ["dp_leaf"]
+print(os.environ.get("CP_LIB_PATH", "base"), "  ".join("%s ms per launch: %.3f (%d)" % (k, p[k]["ms"] / max(p[k]["launches"], 1), p[k]["launches"]) for k in slots))
