@@ -112,6 +112,7 @@ struct RoundCounts {
     int32_t ntile, err;               // cdiv(T, LT); 1: a buffer sized from the prediction is too small (the layer is redone)
     int32_t n_wide, _pad;             // own-tiled tasks of more than FIX_SERIAL tiles (k_fix_own_lane -> k_fix_own)
     int32_t n_glong, n_gslots;        // gap tasks of more than GAPSEG tiles and their segment slots (k_gap_finish -> k_gap_seg)
+    int32_t n_gslow, n_sslow;         // work items of k_gap_finish / k_gap_seg that met a tile with more than SMAX specials (redone by the SLOW variants)
 };
 
 __device__ __forceinline__ void decode_task(const RoundDesc &R, int64_t t, int64_t &r, int &b)
@@ -1100,8 +1101,11 @@ __device__ __forceinline__ double rdl64(double v, int src) { return __longlong_a
 // the tiles [ka, kz) of a task (first tile k0, head B, L steps, row r) walked for NR x 64 rows of the wave (lane l holds the rows
 // rr[0 .. NR-1], one per 64-row chunk: the tile records are fetched once for all of them): the winners so far (bv, bp, bl, bl2)
 // and the specials the rows count so far (cum, cum2) are carried in and out
-template <typename TC, bool HYP, int NR>
-__device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevModel<TC> &M, TC alpha, int64_t ka, int64_t kz, int64_t k0,
+// SLOW = false: the entry-by-entry walk of a tile with more than SMAX specials is compiled out (its column-pointer and cost
+// registers cost the kernels two waves per SIMD, and they wait on memory three quarters of their time): such an item returns false
+// and is redone by the SLOW variant of its kernel.
+template <typename TC, bool HYP, int NR, bool SLOW>
+__device__ __forceinline__ bool gap_walk(const GapCtx<TC, HYP> &C, const DevModel<TC> &M, TC alpha, int64_t ka, int64_t kz, int64_t k0,
                                          int32_t B, int32_t L, int32_t r, int32_t posr, const int32_t (&rr)[NR], const int32_t (&rcmp)[NR],
                                          const bool (&valid)[NR], int lane,
                                          TC (&bv)[NR], int32_t (&bp)[NR], int32_t (&bl)[NR], int32_t (&bl2)[NR], int32_t (&cum)[NR], int32_t (&cum2)[NR])
@@ -1164,6 +1168,8 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
             continue;
         }
         // too many specials: every lane counts for its own rows, entry by entry
+        if (!SLOW) return false;
+        if (SLOW) {
         const int head = k == k0 ? 1 : 0;
         const int32_t pf = B - (int32_t)(k - k0) * LT;
         int32_t tlk = L - (int32_t)(k - k0) * LT; tlk = (tlk < LT ? tlk : LT) - 1;
@@ -1218,8 +1224,10 @@ __device__ __forceinline__ void gap_walk(const GapCtx<TC, HYP> &C, const DevMode
             cum[u] += run[u] - (int32_t)(C.tilePS[k + 1] - C.tilePS[k]);
             if (HYP) cum2[u] += run2[u] - (int32_t)(C.tilePS2[k + 1] - C.tilePS2[k]);
         }
+        }
     }
     }
+    return true;
 }
 
 // rows of the wave, right parts and anchors of a gap task: shared by the kernels below
@@ -1247,24 +1255,26 @@ struct GapSegRec { TC v; int32_t p, l, l2, cum, cum2, _pad; };
 // NR: 64-row chunks per wave (a lane holds one row of each): the task's records -- descriptor, tile winners, segment lists -- are
 // fetched once for NR x 64 rows.  The kernel waits on memory three quarters of its time at four waves per SIMD (profiles/
 // r03_pmc_gap_finish.txt), i.e. it is bound by the number of (task, rows) items times the dependent loads of one item.
-template <typename TC, bool HYP, int NR>
+template <typename TC, bool HYP, int NR, bool SLOW>
 __global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, RoundCounts *__restrict__ rc, int64_t n,
                                                     const int64_t *__restrict__ toffs, GapCtx<TC, HYP> C,
                                                     const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb, const int32_t *__restrict__ rlen,
                                                     const int32_t *__restrict__ prev, const int32_t *__restrict__ lpos, const int32_t *__restrict__ lfirst,
                                                     DevModel<TC> M, TC alpha,
                                                     int32_t *__restrict__ opt, int32_t *__restrict__ nnopt, int32_t *__restrict__ nlopt, uint8_t *__restrict__ fin,
-                                                    int2 *__restrict__ glist, int2 *__restrict__ gslot, int fin_stamp)
+                                                    int2 *__restrict__ glist, int2 *__restrict__ gslot, int fin_stamp, int32_t *__restrict__ slow)
 {
+    // SLOW: the items the fast variant listed in `slow` (rc->n_gslow of them)
     const int lane = threadIdx.x & 63;
     const int nitem = (nchunk + NR - 1) / NR;
-    const int64_t nwork = (int64_t)rc->nown * nitem, n1 = n + 1;
-    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+    const int64_t nwork = SLOW ? (int64_t)rc->n_gslow : (int64_t)rc->nown * nitem, n1 = n + 1;
+    for (int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wi < nwork; wi += (int64_t)gridDim.x * 4) {
+        const int64_t w = SLOW ? (int64_t)slow[wi] : wi;
         const int64_t t = w / nitem;
         const int ck0 = (int)(w - t * nitem) * NR;
         const int64_t k0 = toffs[t], k1 = toffs[t + 1];
         if (k1 - k0 > GAPSEG) {                             // (wave-uniform) a long task: listed for k_gap_seg / k_gap_merge
-            if (ck0 == 0 && lane == 0) {
+            if (!SLOW && ck0 == 0 && lane == 0) {
                 int nseg = (int)((k1 - k0 + GAPSEG - 1) / GAPSEG);
                 int idx = atomicAdd(&rc->n_glong, 1), slot0 = atomicAdd(&rc->n_gslots, nseg);
                 glist[idx] = make_int2((int)t, slot0);
@@ -1295,7 +1305,10 @@ __global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, Roun
         TC bv[NR]; int32_t bp[NR], bl[NR], bl2[NR], cum[NR], cum2[NR];
 #pragma unroll
         for (int u = 0; u < NR; u++) { bv[u] = (TC)0; bp[u] = -1; bl[u] = 0; bl2[u] = 0; cum[u] = 0; cum2[u] = 0; }
-        gap_walk<TC, HYP, NR>(C, M, alpha, k0, k1, k0, B, L, r, posr, rr, rcmp, valid, lane, bv, bp, bl, bl2, cum, cum2);
+        if (!gap_walk<TC, HYP, NR, SLOW>(C, M, alpha, k0, k1, k0, B, L, r, posr, rr, rcmp, valid, lane, bv, bp, bl, bl2, cum, cum2)) {
+            if (lane == 0) slow[atomicAdd(&rc->n_gslow, 1)] = (int32_t)w;
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < NR; u++) {
             if (valid[u]) {
@@ -1310,15 +1323,16 @@ __global__ void __launch_bounds__(256, 4) k_gap_finish(int tau, int nchunk, Roun
 
 // long gap tasks, phase 1: one wave per (segment slot = GAPSEG tiles of a listed task, 64 rows) walks its tiles as if nothing lay
 // in front of them
-template <typename TC, bool HYP>
-__global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, const RoundCounts *__restrict__ rc, int64_t n, const int64_t *__restrict__ toffs,
+template <typename TC, bool HYP, bool SLOW>
+__global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, RoundCounts *__restrict__ rc, int64_t n, const int64_t *__restrict__ toffs,
                                                  GapCtx<TC, HYP> C, const int4 *__restrict__ tdesc, const uint8_t *__restrict__ tb,
                                                  const int32_t *__restrict__ rlen, DevModel<TC> M, TC alpha, const int2 *__restrict__ gslot,
-                                                 GapSegRec<TC, HYP> *__restrict__ gseg)
+                                                 GapSegRec<TC, HYP> *__restrict__ gseg, int32_t *__restrict__ slow)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t nwork = (int64_t)rc->n_gslots * nchunk;
-    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+    const int64_t nwork = SLOW ? (int64_t)rc->n_sslow : (int64_t)rc->n_gslots * nchunk;
+    for (int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wi < nwork; wi += (int64_t)gridDim.x * 4) {
+        const int64_t w = SLOW ? (int64_t)slow[wi] : wi;
         const int64_t slot = w / nchunk;
         const int ck = (int)(w - slot * nchunk);
         const int2 se = gslot[slot];
@@ -1330,7 +1344,10 @@ __global__ void __launch_bounds__(256) k_gap_seg(int tau, int nchunk, const Roun
         TC bv[1] = {(TC)0}; int32_t bp[1] = {-1}, bl[1] = {0}, bl2[1] = {0}, cum[1] = {0}, cum2[1] = {0};
         const int32_t rr1[1] = {g.rr}, rcmp1[1] = {g.rcmp}; const bool valid1[1] = {g.valid};
         const int64_t ka = k0 + (int64_t)sg * GAPSEG, kz = ka + GAPSEG < k1 ? ka + GAPSEG : k1;
-        gap_walk<TC, HYP, 1>(C, M, alpha, ka, kz, k0, td.x, rlen[t], td.z, td.w, rr1, rcmp1, valid1, lane, bv, bp, bl, bl2, cum, cum2);
+        if (!gap_walk<TC, HYP, 1, SLOW>(C, M, alpha, ka, kz, k0, td.x, rlen[t], td.z, td.w, rr1, rcmp1, valid1, lane, bv, bp, bl, bl2, cum, cum2)) {
+            if (lane == 0) slow[atomicAdd(&rc->n_sslow, 1)] = (int32_t)w;
+            continue;
+        }
         GapSegRec<TC, HYP> rec; rec.v = bv[0]; rec.p = bp[0]; rec.l = bl[0]; rec.l2 = bl2[0]; rec.cum = cum[0]; rec.cum2 = cum2[0]; rec._pad = 0;
         gseg[(slot * nchunk + ck) * 64 + lane] = rec;
     }
@@ -2345,6 +2362,7 @@ struct LayerWork {
     DBuf<int2> g_slot;                                  // segment slot -> {task, segment}
     DBuf<int2> g_list;                                  // gap tasks of more than GAPSEG tiles: {task, first segment slot}
     DBuf<char> g_seg;                                   // their segment records (GapSegRec)
+    DBuf<int32_t> g_slow, g_sslow;                      // work items of k_gap_finish / k_gap_seg left to the SLOW variants
     DBuf<int32_t> last_s0;                              // anchors of the last row's round-A tasks ([b], [32 + b])
     DBuf<uint8_t> o_spec, fin;                          // gap passes: flagged tiles; rows already final (per plane slot)
     int fin_stamp = 255;                                // ... iff the cell holds the current layer's stamp (run_layer; 255: cleared before the next layer)
@@ -2603,6 +2621,34 @@ static void win_build(cp_csr_s *A, LayerWork<TC> &Wk)
         CP_HIP(hipGetLastError());
     }
     Wk.win_built = true; Wk.win_w = w;
+}
+
+// the gap round's finishing kernels: fast variants first, then the SLOW ones over what they listed
+template <typename TC, bool HYP>
+static void launch_gap(hipStream_t s, cp_csr_s *A, LayerWork<TC> &Wk, int tau, int nchunk, int gnr, RoundCounts *rc, int64_t n, const TC *W,
+                       const DevModel<TC> &M, TC alpha, unsigned gg, unsigned gs_grid, unsigned gm, unsigned gslow_grid)
+{
+    GapCtx<TC, HYP> C{reinterpret_cast<const Best<TC, HYP> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, HYP> *>(Wk.o_sub.p), Wk.o_spv.p, Wk.o_spec.p,
+                      Wk.o_tilePS.p, HYP ? Wk.o_tilePS2.p : nullptr, A->pos32.p, A->next.p, HYP ? A->fpos32.p : nullptr, HYP ? A->flast.p : nullptr, W};
+    auto *gs = reinterpret_cast<GapSegRec<TC, HYP> *>(Wk.g_seg.p);
+    const int32_t *lp = HYP ? A->lpos32.p : nullptr, *lf = HYP ? A->lfirst.p : nullptr;
+    int32_t *nl = HYP ? Wk.nlopt.p : nullptr;
+#define GF_ARGS tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p, Wk.o_rlen.p, A->prev.p, lp, lf, M, alpha, Wk.opt.p, Wk.nnopt.p, nl, Wk.fin.p, \
+                Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp, Wk.g_slow.p
+    if (gnr == 2) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, HYP, 2, false>), dim3(gg), dim3(256), 0, s, GF_ARGS);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, HYP, 2, true>), dim3(gslow_grid), dim3(256), 0, s, GF_ARGS);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, HYP, 1, false>), dim3(gg), dim3(256), 0, s, GF_ARGS);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, HYP, 1, true>), dim3(gslow_grid), dim3(256), 0, s, GF_ARGS);
+    }
+#undef GF_ARGS
+#define GS_ARGS tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p, Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs, Wk.g_sslow.p
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, HYP, false>), dim3(gs_grid), dim3(256), 0, s, GS_ARGS);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, HYP, true>), dim3(gslow_grid), dim3(256), 0, s, GS_ARGS);
+#undef GS_ARGS
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, HYP>), dim3(gm), dim3(256), 0, s, tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p, A->pos32.p, A->prev.p,
+                       lp, lf, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, nl, Wk.fin.p, Wk.fin_stamp);
 }
 
 constexpr int64_t LB_MAX = 1 << 20;      // largest scan (elements) done in a single launch
@@ -2931,41 +2977,16 @@ static bool run_layer(cp_csr_s *A, const DevModel<TC> &M, TC alpha, const TC *W,
                 const size_t ncap = Wk.o_rec.n / GAPSEG + 2;
                 Wk.g_list.ensure(ncap); Wk.g_slot.ensure(2 * ncap);
                 Wk.g_seg.ensure((2 * ncap) * (size_t)nchunk * 64 * sizeof(GapSegRec<TC, true>));
+                // items that meet a tile with more than SMAX specials are listed by the fast kernels and redone by the SLOW ones
+                Wk.g_slow.ensure((size_t)gown * (size_t)nchunk + 64); Wk.g_sslow.ensure((2 * ncap) * (size_t)nchunk + 64);
+                CP_REQUIRE((int64_t)gown * nchunk < INT32_MAX && (int64_t)(2 * ncap) * nchunk < INT32_MAX, CP_EINTERNAL, "gap work index beyond 32 bits");
                 const int gnr = (g_opt_gap_nr >= 2 && nchunk >= 2) ? 2 : 1;       // 64-row chunks per wave of k_gap_finish
                 unsigned gg = (unsigned)std::min<int64_t>(cdiv(gown * cdiv((int64_t)nchunk, gnr), 4), 16384);
                 unsigned gs_grid = (unsigned)std::min<int64_t>(cdiv((int64_t)(2 * ncap) * nchunk, 4), 8192);
                 unsigned gm = (unsigned)std::min<int64_t>(cdiv((int64_t)ncap * nchunk, 4), 4096);
-                if (hyp) {
-                    GapCtx<TC, true> C{Wk.o_part.p, Wk.o_sub.p, Wk.o_spv.p, Wk.o_spec.p, Wk.o_tilePS.p, Wk.o_tilePS2.p, A->pos32.p, A->next.p, A->fpos32.p, A->flast.p, W};
-                    auto *gs = reinterpret_cast<GapSegRec<TC, true> *>(Wk.g_seg.p);
-                    if (gnr == 2)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
-                    else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, true, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, alpha, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, true>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, true>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       A->pos32.p, A->prev.p, A->lpos32.p, A->lfirst.p, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p, Wk.nlopt.p, Wk.fin.p, Wk.fin_stamp);
-                } else {
-                    GapCtx<TC, false> C{reinterpret_cast<const Best<TC, false> *>(Wk.o_part.p), reinterpret_cast<const Best<TC, false> *>(Wk.o_sub.p), Wk.o_spv.p,
-                                        Wk.o_spec.p, Wk.o_tilePS.p, nullptr, A->pos32.p, A->next.p, nullptr, nullptr, W};
-                    auto *gs = reinterpret_cast<GapSegRec<TC, false> *>(Wk.g_seg.p);
-                    if (gnr == 2)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 2>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
-                    else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_finish<TC, false, 1>), dim3(gg), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, alpha, Wk.opt.p, Wk.nnopt.p, (int32_t *)nullptr,
-                                       Wk.fin.p, Wk.g_list.p, Wk.g_slot.p, Wk.fin_stamp);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_seg<TC, false>), dim3(gs_grid), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, C, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       Wk.o_rlen.p, M, alpha, Wk.g_slot.p, gs);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gap_merge<TC, false>), dim3(gm), dim3(256), 0, s, R.tau, nchunk, rc, n, Wk.o_toffs.p, Wk.o_tdesc.p, Wk.o_tb.p,
-                                       A->pos32.p, A->prev.p, (const int32_t *)nullptr, (const int32_t *)nullptr, M, Wk.g_list.p, gs, Wk.opt.p, Wk.nnopt.p,
-                                       (int32_t *)nullptr, Wk.fin.p, Wk.fin_stamp);
-                }
+                const unsigned gslow_grid = 2048;                               // (grid-stride over the device-side counts n_gslow / n_sslow: usually none)
+                if (hyp) launch_gap<TC, true>(s, A, Wk, R.tau, nchunk, gnr, rc, n, W, M, alpha, gg, gs_grid, gm, gslow_grid);
+                else launch_gap<TC, false>(s, A, Wk, R.tau, nchunk, gnr, rc, n, W, M, alpha, gg, gs_grid, gm, gslow_grid);
             } else {
                 ProfScope ps(PROF_FIX, s, 24.0 * (double)P.NT);
                 // one lane per task: single tiles are final already, short tasks are merged on the spot, the rest is listed
