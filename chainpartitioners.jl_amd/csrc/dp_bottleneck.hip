@@ -164,7 +164,17 @@ __global__ void __launch_bounds__(256) k_bn_starts(BnCtx<TC> C, int64_t rlo, int
         if (lo > hi) lo = hi;
     } else if (hint) {
         int64_t g = hint[t];
-        if (hint2) g += g - (int64_t)hint2[t];                // (the crossing of the layer before as well: continue its move)
+        if (hint2) {
+            // the crossing of the layer before as well: continue its move.  The last part of a prefix shrinks like 1 / k with the number
+            // of parts k (s_k = r - c_k(r) ~ r / k): rho = s_k / s_(k-1) = (k - 1) / k gives s_(k+1) = s_k k / (k + 1) = s_k / (2 - rho)
+            // without knowing k -- a linear continuation is off by thousands of columns in the first dozen layers (a dozen probes of 24
+            // dependent levels each per start), this one by a few hundred.  Only a hint: any value is safe.
+            const int64_t h2 = hint2[t], s1 = r - g, s2 = r - h2;
+            if (s1 > 0 && s2 >= s1) {
+                const double rho = (double)s1 / (double)s2;
+                g = r - (int64_t)((double)s1 / (2.0 - rho));
+            } else g += g - h2;
+        }
         if (g < lo0) g = lo0;
         if (g > phi) g = phi;
         const int64_t d0 = slack > 0 ? slack : 1;          // first gallop step
