@@ -726,6 +726,7 @@ int32_t cp_set_option(const char *name, int64_t value)
     if (!strcmp(name, "gap_tau")) { g_opt_gap_tau = value > 20 ? 20 : value; return CP_OK; }
     if (!strcmp(name, "gap_min")) { g_opt_gap_min = value < 8 ? 8 : value; return CP_OK; }
     if (!strcmp(name, "gap_nr")) { g_opt_gap_nr = value >= 2 ? 2 : 1; return CP_OK; }
+    if (!strcmp(name, "pool")) { g_opt_pool = value ? 1 : 0; if (!value) dev_pool_trim(); return CP_OK; }      // (1: keep freed device blocks >= 1 MB for reuse; 0: return them)
     if (!strcmp(name, "ra_cache")) { g_opt_ra_cache = value; return CP_OK; }
     if (!strcmp(name, "leaf")) { g_opt_leaf = value; return CP_OK; }
     if (!strcmp(name, "poison")) { g_opt_poison = value; if (value) { g_poison_hits = 0; g_spec_redo = 0; } return CP_OK; }

@@ -42,6 +42,17 @@ struct HipFail { int32_t code; };
     catch (const std::bad_alloc &) { cpk::set_error("host allocation failed"); return CP_EHIP; }
 
 // ------------------------------------------------------------------ device buffers (RAII)
+// Allocations of 1 MB and more go through a per-process pool keyed by (device, exact byte size): the builds and drivers allocate the
+// same multi-hundred-MB temporaries in every call, and handing them back to the HIP runtime each time makes it stall for ~1.3 s
+// once per ~50 GB of such churn (tools/stall_probe.py: every ~20th link build; a 0.1 s bottleneck partition then takes 1 s).
+// A block freed while its stream still runs kernels is only ever handed to work enqueued LATER by the next call -- every entry
+// point synchronises its stream before it returns -- so reuse is stream-ordered.  cp_set_option("pool", 0) turns the pool off and
+// returns what it holds; over 48 GB it empties itself; a failed hipMalloc empties it and retries.
+void *dev_alloc(size_t bytes);
+void dev_free(void *p, size_t bytes);
+void dev_pool_trim();
+extern int64_t g_opt_pool;
+
 template <typename T>
 struct DBuf {
     T *p = nullptr;
@@ -55,11 +66,11 @@ struct DBuf {
     ~DBuf() { release(); }
     void alloc(size_t count) {
         release();
-        if (count) CP_HIP(hipMalloc((void **)&p, count * sizeof(T)));      // (throws with n == 0, p == nullptr: a failed buffer never claims a size)
+        if (count) p = (T *)dev_alloc(count * sizeof(T));      // (throws with n == 0, p == nullptr: a failed buffer never claims a size)
         n = count;
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void release() { if (p) { dev_free(p, n * sizeof(T)); p = nullptr; } n = 0; }
     size_t bytes() const { return n * sizeof(T); }
 };
 

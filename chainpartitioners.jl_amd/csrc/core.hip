@@ -6,6 +6,8 @@
 // reference's idx'[q] equals (n+1) - (prev[q] + 1).
 #include "csr.hpp"
 #include <rocprim/rocprim.hpp>
+#include <map>
+#include <mutex>
 
 namespace cpk {
 
@@ -33,6 +35,70 @@ void prof_collect()
         g_event_pool.push_back(p.b);
     }
     g_prof_pending.clear();
+}
+
+// ------------------------------------------------------------------ pooled device allocations (common.hpp: DBuf)
+namespace {
+// (never destroyed: buffers owned by objects with static lifetime may be released after this file's statics are gone)
+std::mutex &g_pool_mu = *new std::mutex;
+std::map<std::pair<int, size_t>, std::vector<void *>> &g_pool = *new std::map<std::pair<int, size_t>, std::vector<void *>>;      // (device, bytes) -> free blocks
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MIN = (size_t)1 << 20, POOL_CAP = (size_t)48 << 30;
+}
+int64_t g_opt_pool = 1;
+
+static void pool_trim_locked()
+{
+    for (auto &kv : g_pool) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != kv.first.first) (void)hipSetDevice(kv.first.first);
+        for (void *p : kv.second) (void)hipFree(p);
+        if (cur != kv.first.first) (void)hipSetDevice(cur);
+    }
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+void dev_pool_trim() { std::lock_guard<std::mutex> lk(g_pool_mu); pool_trim_locked(); }
+
+void *dev_alloc(size_t bytes)
+{
+    int dev = 0;
+    if (bytes >= POOL_MIN && g_opt_pool) {
+        CP_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool.find({dev, bytes});
+        if (it != g_pool.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            g_pool_bytes -= bytes;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                               // out of memory with blocks parked in the pool: give them back and try once more
+        (void)hipGetLastError();
+        dev_pool_trim();
+        CP_HIP(hipMalloc(&p, bytes));
+    }
+    return p;
+}
+
+void dev_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= POOL_MIN && g_opt_pool) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            if (g_pool_bytes + bytes > POOL_CAP) pool_trim_locked();
+            g_pool[{dev, bytes}].push_back(p);
+            g_pool_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 // ------------------------------------------------------------------ exclusive scan int32 -> int64

@@ -239,7 +239,7 @@ int32_t cp_get_stat(const char *name, int64_t *out);
 /* Library-wide tunables and test switches; results never depend on them (tests/test_gpu_dynamic.py runs every one against the
  * oracle).  "force_brute" 1: the general O(K n^2) device DP even where the O(K n log^2 n) scheme applies; "brute_max_n": its size
  * limit.  Layer driver of the O(K n log^2 n) scheme: "short_t"/"short_e" (tasks finished during setup),
- * "own_min" (shortest task with tiles of its own), "gap_tau"/"gap_min" (gap passes: rounds and task lengths; -1: none), "gap_nr" (64-row chunks per wave of the gap finish: 1 or 2),
+ * "own_min" (shortest task with tiles of its own), "gap_tau"/"gap_min" (gap passes: rounds and task lengths; -1: none), "gap_nr" (64-row chunks per wave of the gap finish: 1 or 2), "pool" (1, default: freed device blocks of 1 MB and more are kept for reuse by the next call; 0: returned to HIP at once, and the pool is emptied),
  * "ra_cache" (round A from counts cached per partition), "nospec" 1 (one host sync per round instead of sizing a layer from the
  * previous one), "rpass_ch"/"rpass_small_tau"/"rpass_cap" (right-part passes: columns per wave, last
  * lane-per-row round, lane-private share of a row in per cent of the mean), "setup_bs" (lanes per block of the task setup), "force_max" (a round whose flattened

@@ -175,3 +175,23 @@ def test_plain_c_client_runs(hip):
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "c_abi_demo"], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(root, "examples", "c_abi_demo")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def test_device_block_pool_on_and_off(hip, orc):
+    """cp_set_option("pool", ...): freed device blocks of 1 MB and more are kept for the next call (csrc/core.hip dev_alloc) -- the same
+    answers with the pool off, after it was emptied, and on again with recycled (non-zero) blocks"""
+    A = suitesparse_shaped(60000, 8, 77)          # (large enough for blocks above the pool's 1 MB threshold)
+    mdl = MODELS[1]
+    want = None
+    try:
+        for pool in (1, 0, 1, 1):
+            assert hip.set_option("pool", pool) == 0
+            got = [cp.partition_stripe(A, 5, cp.DynamicTotalSplitter(cp.ConstrainedCost(mdl, cp.VertexCount(), 20000)), backend=hip),
+                   cp.partition_stripe(A, 5, cp.DynamicBottleneckSplitter(mdl), backend=hip),
+                   cp.partition_stripe(A, 7, cp.BisectCostBottleneckSplitter(mdl, 0.01), backend=hip)]
+            if want is None:
+                want = got
+            assert got == want
+    finally:
+        hip.set_option("pool", 1)
+    assert want[1] == cp.partition_stripe(A, 5, cp.DynamicBottleneckSplitter(mdl), backend=orc)
