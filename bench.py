@@ -429,7 +429,8 @@ def run_dp(args, cfg, dev, rank, world, dist):
         "dtype": "int64", "data": "synthetic",
         "config": {"workload": "config %s: %s on suitesparse_shaped CSR (seeded SplitMix64 generator, tests/synth.py), n=%d rows, nnz=%d, K=%d; %s"
                                % (cfg, B.method_name(), n, N, K, "one partition, DP rows tiled over the GPUs" if tiled else "one independent partition per GPU"),
-                   "n": n, "nnz": N, "K": K, "includes_oracle_build": True},
+                   "n": n, "nnz": N, "K": K, "includes_oracle_build": True,
+                   "device_block_pool": True},      # (every step rebuilds the oracle structures; the raw device blocks they live in are recycled: csrc/core.hip dev_alloc)
         "roofline": {"bound": "hbm", "kernel": "%s (%s)" % (dom, kname), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "measured_copy_gbs": copy_gbs,      # this box's device-to-device copy rate (read + write bytes), SURVEY 8(d)
