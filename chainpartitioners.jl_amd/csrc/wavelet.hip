@@ -34,14 +34,24 @@ __global__ void __launch_bounds__(256) k_hist_keys(const int32_t *__restrict__ k
     if (key >= 0 && !is_hot) atomicAdd(&hist[key], 1);
 }
 
+// (eight 64-key words per wave, their loads issued together: with one key per thread the 390 000 blocks of a level at N = 10^8 spent
+//  their time being launched -- 0.20 ms per level for a 400 MB read)
+constexpr int WT_E = 8;
 __global__ void __launch_bounds__(256) k_wt_bits(const int32_t *__restrict__ keys, int64_t Nk, int h, int64_t W,
                                                  uint64_t *__restrict__ byt, int32_t *__restrict__ popc)
 {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int bit = (q < Nk) ? ((keys[q] >> (h - 1)) & 1) : 0;
-    unsigned long long m = __ballot(bit);
-    int64_t w = q >> 6;
-    if ((threadIdx.x & 63) == 0 && w < W) { byt[w] = m; popc[w] = __popcll(m); }
+    const int64_t base = ((int64_t)blockIdx.x * WT_E) * blockDim.x + threadIdx.x;
+    int32_t k[WT_E];
+#pragma unroll
+    for (int e = 0; e < WT_E; e++) { const int64_t q = base + (int64_t)e * blockDim.x; k[e] = q < Nk ? keys[q] : 0; }
+#pragma unroll
+    for (int e = 0; e < WT_E; e++) {
+        const int64_t q = base + (int64_t)e * blockDim.x;
+        const int bit = (k[e] >> (h - 1)) & 1;                 // (keys beyond Nk were read as 0)
+        const unsigned long long m = __ballot(bit);
+        const int64_t w = q >> 6;
+        if ((threadIdx.x & 63) == 0 && w < W) { byt[w] = m; popc[w] = __popcll(m); }
+    }
 }
 
 __device__ __forceinline__ int64_t ones_before(const uint64_t *__restrict__ byt, const int32_t *__restrict__ cnt, int64_t x)
@@ -53,16 +63,23 @@ __global__ void __launch_bounds__(256) k_wt_scatter(const int32_t *__restrict__ 
                                                     const uint64_t *__restrict__ byt, const int32_t *__restrict__ cnt,
                                                     const int32_t *__restrict__ qos0)
 {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Nk) return;
-    int32_t key = keys[q];
-    int64_t bucket = (int64_t)key >> h;
-    int64_t s = qos0[bucket << h], e = qos0[(bucket + 1) << h];
-    int64_t ob_q = ones_before(byt, cnt, q), ob_s = ones_before(byt, cnt, s), ob_e = ones_before(byt, cnt, e);
-    int64_t zeros_in_bucket = (e - s) - (ob_e - ob_s);
-    int d = (key >> (h - 1)) & 1;
-    int64_t np = d ? s + zeros_in_bucket + (ob_q - ob_s) : s + ((q - ob_q) - (s - ob_s));
-    out[np] = key;
+    const int64_t base = ((int64_t)blockIdx.x * WT_E) * blockDim.x + threadIdx.x;
+    int32_t k[WT_E];
+#pragma unroll
+    for (int e = 0; e < WT_E; e++) { const int64_t q = base + (int64_t)e * blockDim.x; k[e] = q < Nk ? keys[q] : 0; }
+#pragma unroll
+    for (int e = 0; e < WT_E; e++) {
+        const int64_t q = base + (int64_t)e * blockDim.x;
+        if (q >= Nk) continue;
+        const int32_t key = k[e];
+        int64_t bucket = (int64_t)key >> h;
+        int64_t s = qos0[bucket << h], en = qos0[(bucket + 1) << h];
+        int64_t ob_q = ones_before(byt, cnt, q), ob_s = ones_before(byt, cnt, s), ob_e = ones_before(byt, cnt, en);
+        int64_t zeros_in_bucket = (en - s) - (ob_e - ob_s);
+        int d = (key >> (h - 1)) & 1;
+        int64_t np = d ? s + zeros_in_bucket + (ob_q - ob_s) : s + ((q - ob_q) - (s - ob_s));
+        out[np] = key;
+    }
 }
 
 // The key histogram of the net counter without atomics: key n - c counts the entries whose PREVIOUS occurrence lies in column c,
@@ -122,10 +139,10 @@ void wavelet_build(WaveletHost &WT, DBuf<int32_t> &keys, int64_t Nk, int32_t H, 
         uint64_t *bv = WT.byt.p + (size_t)(h - 1) * W;
         int32_t *cv = WT.cnt.p + (size_t)(h - 1) * (W + 1);
         CP_HIP(hipMemsetAsync(popc.p, 0, popc.bytes(), s));
-        hipLaunchKernelGGL(k_wt_bits, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, cur, Nk, h, W, bv, popc.p);
+        hipLaunchKernelGGL(k_wt_bits, dim3((unsigned)cdiv(Nk, 256 * WT_E)), dim3(256), 0, s, cur, Nk, h, W, bv, popc.p);
         exclusive_scan_i32_i32(popc.p, cv, W, scratch, s);
         if (h > 1) {
-            hipLaunchKernelGGL(k_wt_scatter, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, cur, oth, Nk, h, bv, cv, WT.qos0.p);
+            hipLaunchKernelGGL(k_wt_scatter, dim3((unsigned)cdiv(Nk, 256 * WT_E)), dim3(256), 0, s, cur, oth, Nk, h, bv, cv, WT.qos0.p);
             int32_t *t = cur; cur = oth; oth = t;
         }
     }
@@ -298,7 +315,7 @@ static void wsum_build(cp_wsum_s *Wd, DBuf<int32_t> &keys, const TW *w_dev, int6
         uint64_t *bv = WT.byt.p + (size_t)(h - 1) * W;
         int32_t *cv = WT.cnt.p + (size_t)(h - 1) * (W + 1);
         CP_HIP(hipMemsetAsync(popc.p, 0, popc.bytes(), s));
-        hipLaunchKernelGGL(k_wt_bits, dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, cur, Nk, h, W, bv, popc.p);
+        hipLaunchKernelGGL(k_wt_bits, dim3((unsigned)cdiv(Nk, 256 * WT_E)), dim3(256), 0, s, cur, Nk, h, W, bv, popc.p);
         exclusive_scan_i32_i32(popc.p, cv, W, scratch, s);
         wsum_scan<TW>(wc, cur, h - 1, Nk, reinterpret_cast<TW *>(Wd->Z.p) + (size_t)(h - 1) * (size_t)(Nk + 1), wscr, s);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wt_scatter_w<TW>), dim3((unsigned)cdiv(Nk, 256)), dim3(256), 0, s, cur, oth, wc, wo, Nk, h, bv, cv, WT.qos0.p);
