@@ -720,7 +720,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL 2.26 prints a version banner on rank 0's stdout when its communicator comes up (a C printf, flushed at once): stdout
+        # carries the ONE JSON line, so file descriptor 1 points at stderr until the group exists and has run its first collective
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
